@@ -1,0 +1,25 @@
+# Builds everything in-tree:  make            (oracle + synth harness + HIP library)
+#   sg-slam_amd/lib/libsgs_hip.so    product: HIP kernels + C ABI (include/sgs.h), gfx950 only
+#   sg-slam_amd/lib/libsgs_synth.so  harness: synthetic LiDAR scan generator (host only)
+#   oracle/liboracle.so              test infrastructure: CPU restatement of the reference path
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+PKG := sg-slam_amd
+HIP_SRCS := $(wildcard $(PKG)/csrc/*.hip)
+HIP_HDRS := $(wildcard $(PKG)/csrc/*.h $(PKG)/csrc/*.hpp include/*.h)
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/csrc -Wall -Wno-unused-result
+
+all: oracle synth hip
+oracle:
+	$(MAKE) -C oracle
+synth: $(PKG)/lib/libsgs_synth.so
+hip: $(PKG)/lib/libsgs_hip.so
+$(PKG)/lib/libsgs_synth.so: $(PKG)/csrc/synth.cpp
+	@mkdir -p $(PKG)/lib
+	$(CXX) -O2 -std=c++17 -fPIC -fopenmp -shared -o $@ $<
+$(PKG)/lib/libsgs_hip.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+clean:
+	rm -f $(PKG)/lib/*.so oracle/liboracle.so
+.PHONY: all oracle synth hip clean

@@ -1,0 +1,349 @@
+// ORACLE (test infrastructure, NOT product code): C entry points over the CPU restatement in
+// sgo_core.hpp so that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive
+// it through ctypes.  Nothing under sg-slam_amd/ may link, load or call this library.
+// PARITY UNPINNED (see sgo_core.hpp header).
+#include <cstdio>
+#include <cstring>
+
+#include "sgo_core.hpp"
+
+using namespace sgo;
+
+extern "C" {
+
+// pose layout across this ABI: [qx, qy, qz, qw, tx, ty, tz]
+static SE3 pose_in(const double *p) {
+    SE3 T;
+    T.q = Quat{p[3], p[0], p[1], p[2]};
+    T.t = Vec3(p[4], p[5], p[6]);
+    return T;
+}
+static void pose_out(const SE3 &T, double *p) {
+    p[0] = T.q.x; p[1] = T.q.y; p[2] = T.q.z; p[3] = T.q.w;
+    p[4] = T.t.x; p[5] = T.t.y; p[6] = T.t.z;
+}
+static std::vector<Vec3> vec3_in(const double *xyz, int n) {
+    std::vector<Vec3> v((size_t)n);
+    for (int i = 0; i < n; ++i) v[(size_t)i] = Vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return v;
+}
+static std::vector<P4> p4_in(const double *xyzl, int n) {
+    std::vector<P4> v((size_t)n);
+    for (int i = 0; i < n; ++i) v[(size_t)i] = P4{xyzl[4 * i], xyzl[4 * i + 1], xyzl[4 * i + 2], xyzl[4 * i + 3]};
+    return v;
+}
+
+void sgo_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int sgo_get_max_threads() { return omp_get_max_threads(); }
+
+// ---- SE3 helpers (so tests can pin exp/log against scipy) ----
+void sgo_se3_exp(const double *tangent6, double *pose7) {
+    Vec6 a;
+    for (int i = 0; i < 6; ++i) a.v[i] = tangent6[i];
+    pose_out(se3_exp(a), pose7);
+}
+void sgo_se3_log(const double *pose7, double *tangent6) {
+    const Vec6 a = se3_log(pose_in(pose7));
+    for (int i = 0; i < 6; ++i) tangent6[i] = a.v[i];
+}
+void sgo_se3_mul(const double *a7, const double *b7, double *out7) { pose_out(pose_in(a7) * pose_in(b7), out7); }
+void sgo_se3_inv(const double *a7, double *out7) { pose_out(inverse(pose_in(a7)), out7); }
+void sgo_se3_act(const double *a7, const double *xyz, int n, double *out) {
+    const SE3 T = pose_in(a7);
+    for (int i = 0; i < n; ++i) {
+        const Vec3 w = T * Vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        out[3 * i] = w.x; out[3 * i + 1] = w.y; out[3 * i + 2] = w.z;
+    }
+}
+void sgo_ldlt6_solve(const double *A36, const double *b6, double *x6) {
+    double A[6][6];
+    std::memcpy(A, A36, sizeof(A));
+    ldlt6_solve(A, b6, x6);
+}
+void sgo_sym_eig(int n, const double *a_in, double *evals, double *evecs) {
+    std::vector<double> a(a_in, a_in + (size_t)n * n), d;
+    sym_eig(n, a, d);
+    std::memcpy(evals, d.data(), sizeof(double) * (size_t)n);
+    std::memcpy(evecs, a.data(), sizeof(double) * (size_t)n * n);
+}
+
+// ---- stage functions ----
+void sgo_voxel_keys(const double *xyz, int n, double voxel, int32_t *keys) {
+    for (int i = 0; i < n; ++i) {
+        const Key3 k = voxel_key(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], voxel);
+        keys[3 * i] = k.x; keys[3 * i + 1] = k.y; keys[3 * i + 2] = k.z;
+    }
+}
+uint32_t sgo_voxel_hash(int32_t x, int32_t y, int32_t z) { return voxel_hash(Key3{x, y, z}); }
+
+int sgo_preprocess(const double *xyz, const int32_t *label, int n, double max_range,
+                   double min_range, double *out_xyz, int32_t *out_label) {
+    std::vector<int> lab(label, label + n);
+    const Cloud c = preprocess_semantic(vec3_in(xyz, n), lab, max_range, min_range);
+    for (size_t i = 0; i < c.size(); ++i) {
+        out_xyz[3 * i] = c.p[i].x; out_xyz[3 * i + 1] = c.p[i].y; out_xyz[3 * i + 2] = c.p[i].z;
+        out_label[i] = c.l[i];
+    }
+    return (int)c.size();
+}
+void sgo_correct_kitti(const double *xyz, int n, double *out) {
+    const auto r = correct_kitti_scan(vec3_in(xyz, n));
+    for (int i = 0; i < n; ++i) { out[3 * i] = r[(size_t)i].x; out[3 * i + 1] = r[(size_t)i].y; out[3 * i + 2] = r[(size_t)i].z; }
+}
+void sgo_deskew(const double *xyz, const double *ts, int n, const double *start7,
+                const double *finish7, double *out) {
+    std::vector<double> t(ts, ts + n);
+    const auto r = deskew_scan(vec3_in(xyz, n), t, pose_in(start7), pose_in(finish7));
+    for (int i = 0; i < n; ++i) { out[3 * i] = r[(size_t)i].x; out[3 * i + 1] = r[(size_t)i].y; out[3 * i + 2] = r[(size_t)i].z; }
+}
+// info4: [buckets, max_dist, grow_by_probe, wrapped]
+int sgo_voxel_downsample(const double *xyz, const int32_t *label, int n, double voxel,
+                         int order_mode, int64_t probe_limit, double *out_xyz, int32_t *out_label,
+                         int32_t *out_index, int64_t *info4) {
+    Cloud in;
+    in.p = vec3_in(xyz, n);
+    in.l.assign(label, label + n);
+    std::vector<int> idx;
+    DownsampleInfo info;
+    const Cloud c = voxel_downsample_semantic(in, voxel, order_mode, &idx, &info, probe_limit);
+    for (size_t i = 0; i < c.size(); ++i) {
+        if (out_xyz) { out_xyz[3 * i] = c.p[i].x; out_xyz[3 * i + 1] = c.p[i].y; out_xyz[3 * i + 2] = c.p[i].z; }
+        if (out_label) out_label[i] = c.l[i];
+        if (out_index) out_index[i] = idx[i];
+    }
+    if (info4) { info4[0] = info.buckets; info4[1] = info.max_dist; info4[2] = info.grow_by_probe; info4[3] = info.wrapped; }
+    return (int)c.size();
+}
+
+// ---- voxel map ----
+void *sgo_map_create(double voxel, double max_dist, int cap, int prune_mode) {
+    auto *m = new VoxelHashMap(voxel, max_dist, cap);
+    m->prune_mode_ = prune_mode;
+    return m;
+}
+void sgo_map_destroy(void *h) { delete (VoxelHashMap *)h; }
+void sgo_map_clear(void *h) { ((VoxelHashMap *)h)->Clear(); }
+int sgo_map_empty(void *h) { return ((VoxelHashMap *)h)->Empty() ? 1 : 0; }
+void sgo_map_add_points(void *h, const double *xyzl, int n) { ((VoxelHashMap *)h)->AddPoints(p4_in(xyzl, n)); }
+void sgo_map_update(void *h, const double *xyzl, int n, const double *pose7) {
+    ((VoxelHashMap *)h)->Update(p4_in(xyzl, n), pose_in(pose7));
+}
+void sgo_map_prune(void *h, const double *origin3) {
+    ((VoxelHashMap *)h)->RemovePointsFarFromLocation(Vec3(origin3[0], origin3[1], origin3[2]));
+}
+void sgo_map_size(void *h, int *voxels, int *points) {
+    auto *m = (VoxelHashMap *)h;
+    int np = 0;
+    for (const auto &b : m->map_.buckets())
+        if (b.dist >= 0) np += (int)b.value.points.size();
+    *voxels = (int)m->map_.size();
+    *points = np;
+}
+// Pointcloud() in reference (bucket) order
+int sgo_map_pointcloud(void *h, double *xyzl, int cap) {
+    const auto pc = ((VoxelHashMap *)h)->Pointcloud();
+    const int n = (int)pc.size() < cap ? (int)pc.size() : cap;
+    for (int i = 0; i < n; ++i) { xyzl[4 * i] = pc[(size_t)i].x; xyzl[4 * i + 1] = pc[(size_t)i].y; xyzl[4 * i + 2] = pc[(size_t)i].z; xyzl[4 * i + 3] = pc[(size_t)i].l; }
+    return (int)pc.size();
+}
+// canonical dump: voxels sorted by (x,y,z) key; keys nv*3, counts nv, points nv*cap*4 (insertion order)
+int sgo_map_dump(void *h, int max_voxels, int32_t *keys, int32_t *counts, double *points) {
+    auto *m = (VoxelHashMap *)h;
+    std::vector<const RobinMap<VoxelBlock>::Bucket *> bs;
+    for (const auto &b : m->map_.buckets())
+        if (b.dist >= 0) bs.push_back(&b);
+    std::sort(bs.begin(), bs.end(), [](auto *a, auto *b) {
+        if (a->key.x != b->key.x) return a->key.x < b->key.x;
+        if (a->key.y != b->key.y) return a->key.y < b->key.y;
+        return a->key.z < b->key.z;
+    });
+    const int cap = m->max_points_per_voxel_;
+    const int nv = (int)bs.size() < max_voxels ? (int)bs.size() : max_voxels;
+    for (int i = 0; i < nv; ++i) {
+        keys[3 * i] = bs[(size_t)i]->key.x; keys[3 * i + 1] = bs[(size_t)i]->key.y; keys[3 * i + 2] = bs[(size_t)i]->key.z;
+        const auto &pts = bs[(size_t)i]->value.points;
+        counts[i] = (int)pts.size();
+        for (int j = 0; j < cap; ++j) {
+            double *o = points + ((size_t)i * cap + j) * 4;
+            if (j < (int)pts.size()) { o[0] = pts[(size_t)j].x; o[1] = pts[(size_t)j].y; o[2] = pts[(size_t)j].z; o[3] = pts[(size_t)j].l; }
+            else { o[0] = o[1] = o[2] = o[3] = 0; }
+        }
+    }
+    return (int)bs.size();
+}
+// returns m; src/tgt m*4; query_index m; *candidates = total candidates visited
+int sgo_map_get_correspondences(void *h, const double *xyzl, int n, double max_dist, double *src,
+                                double *tgt, int32_t *query_index, int64_t *candidates) {
+    const Correspondences c = ((VoxelHashMap *)h)->GetCorrespondences(p4_in(xyzl, n), max_dist);
+    for (size_t i = 0; i < c.src.size(); ++i) {
+        if (src) { src[4 * i] = c.src[i].x; src[4 * i + 1] = c.src[i].y; src[4 * i + 2] = c.src[i].z; src[4 * i + 3] = c.src[i].l; }
+        if (tgt) { tgt[4 * i] = c.tgt[i].x; tgt[4 * i + 1] = c.tgt[i].y; tgt[4 * i + 2] = c.tgt[i].z; tgt[4 * i + 3] = c.tgt[i].l; }
+        if (query_index) query_index[i] = c.query_index[i];
+    }
+    if (candidates) *candidates = c.candidates;
+    return (int)c.src.size();
+}
+// 27 unique scalars: JTJ upper triangle row-major (21) then JTr (6)
+int sgo_build_linear_system(void *h, const double *xyzl_world, int n, double max_dist, double kernel,
+                            double *out27) {
+    const Correspondences c = ((VoxelHashMap *)h)->GetCorrespondences(p4_in(xyzl_world, n), max_dist);
+    const LinearSystem L = build_linear_system(c.src, c.tgt, kernel);
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) out27[k++] = L.JTJ[a][b];
+    for (int a = 0; a < 6; ++a) out27[k++] = L.JTr[a];
+    return (int)c.src.size();
+}
+// info3: [iterations, candidates, correspondences]
+void sgo_register_frame(void *h, const double *xyzl, int n, const double *guess7, double max_corr,
+                        double kernel, double *out_pose7, int64_t *info3) {
+    IcpInfo info;
+    const SE3 T = register_frame_semantic(p4_in(xyzl, n), *(VoxelHashMap *)h, pose_in(guess7), max_corr, kernel, &info);
+    pose_out(T, out_pose7);
+    if (info3) { info3[0] = info.iterations; info3[1] = info.candidates; info3[2] = info.correspondences; }
+}
+
+// ---- clustering / graph ----
+// boxes: nb * 8 doubles [cx,cy,cz,dx,dy,dz,label,points_num]; point_cluster: n (cluster id per point, 0 if not foreground)
+int sgo_cluster_points(const double *xyz, const int32_t *label, int n, double dA, double dR, double dP,
+                       int max_boxes, double *boxes, int32_t *point_cluster, int32_t *n_fg, int32_t *n_bg) {
+    std::vector<int> lab(label, label + n), pcid;
+    Cloud bg, fg;
+    const auto bb = cluster_points(vec3_in(xyz, n), lab, bg, fg, dA, dR, dP, &pcid);
+    const int nb = (int)bb.size() < max_boxes ? (int)bb.size() : max_boxes;
+    for (int i = 0; i < nb; ++i) {
+        double *o = boxes + 8 * (size_t)i;
+        o[0] = bb[(size_t)i].center.x; o[1] = bb[(size_t)i].center.y; o[2] = bb[(size_t)i].center.z;
+        o[3] = bb[(size_t)i].dimension.x; o[4] = bb[(size_t)i].dimension.y; o[5] = bb[(size_t)i].dimension.z;
+        o[6] = bb[(size_t)i].label; o[7] = bb[(size_t)i].points_num;
+    }
+    if (point_cluster) for (int i = 0; i < n; ++i) point_cluster[i] = pcid[(size_t)i];
+    if (n_fg) *n_fg = (int)fg.size();
+    if (n_bg) *n_bg = (int)bg.size();
+    return (int)bb.size();
+}
+static std::vector<Bbox> boxes_in(const double *boxes, int nb) {
+    std::vector<Bbox> v((size_t)nb);
+    for (int i = 0; i < nb; ++i) {
+        const double *o = boxes + 8 * (size_t)i;
+        v[(size_t)i].center = Vec3(o[0], o[1], o[2]);
+        v[(size_t)i].dimension = Vec3(o[3], o[4], o[5]);
+        v[(size_t)i].label = (int)o[6];
+        v[(size_t)i].points_num = (int)o[7];
+    }
+    return v;
+}
+// desc: nb*(3*subinterval+dim) floats; edge_matrix nb*nb; evals nb; edges: up to max_edges pairs;
+// tri_counts nb (number of sub-triangles per node); triangles: concatenated 3 doubles each (max_tri)
+int sgo_build_graph(const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
+                    double subgraph_edge_th, float *desc, double *edge_matrix, double *evals,
+                    int max_edges, int32_t *edges, double *edge_value, double *edge_weights,
+                    int32_t *tri_counts, int max_tri, double *triangles, int32_t *counts3) {
+    const Graph g = build_graph(boxes_in(boxes, nb), edge_dis_th, subinterval, dim, subgraph_edge_th);
+    const int D = 3 * subinterval + dim;
+    if (desc) for (int i = 0; i < (int)g.node_desc.size(); ++i) std::memcpy(desc + (size_t)i * D, g.node_desc[(size_t)i].data(), sizeof(float) * (size_t)D);
+    if (edge_matrix && nb) std::memcpy(edge_matrix, g.edge_matrix.data(), sizeof(double) * (size_t)nb * nb);
+    if (evals && nb) std::memcpy(evals, g.eigenvalues.data(), sizeof(double) * (size_t)nb);
+    const int ne = (int)g.edges.size();
+    for (int i = 0; i < ne && i < max_edges; ++i) {
+        if (edges) { edges[2 * i] = g.edges[(size_t)i].first; edges[2 * i + 1] = g.edges[(size_t)i].second; }
+        if (edge_value) edge_value[i] = g.edge_value[(size_t)i];
+        if (edge_weights) edge_weights[i] = g.edge_weights[(size_t)i];
+    }
+    int nt = 0;
+    for (int i = 0; i < nb; ++i) {
+        const auto &t = g.node_sub_triangles[(size_t)i];
+        if (tri_counts) tri_counts[i] = (int)t.size();
+        for (const Vec3 &v : t) {
+            if (triangles && nt < max_tri) { triangles[3 * nt] = v.x; triangles[3 * nt + 1] = v.y; triangles[3 * nt + 2] = v.z; }
+            ++nt;
+        }
+    }
+    if (counts3) { counts3[0] = g.vehicle_num; counts3[1] = g.trunk_num; counts3[2] = g.pole_like_num; }
+    return ne;
+}
+
+// ---- pipeline ----
+struct sgo_config {  // plain mirror of sgo::Config for ctypes
+    double voxel_size, voxel_size_cluster, max_range, min_range;
+    int32_t max_points_per_voxel;
+    double min_motion_th, initial_threshold;
+    double model_deviation_trans, model_deviation_rot, inlier_rate_th;
+    int32_t deskew, relocalization_enable;
+    double deltaA, deltaR, deltaP;
+    double edge_dis_th, subgraph_edge_th;
+    int32_t subinterval, graph_node_dimension;
+    double nn_vehicle, nn_pole, max_local_graph_map_range;
+    int32_t order_mode, prune_mode, enable_graph, reserved;
+};
+struct SlamHandle {
+    SemGraphSLAM slam;
+    ScanOutput last;
+    explicit SlamHandle(const Config &c) : slam(c) {}
+};
+void *sgo_slam_create(const sgo_config *c) {
+    Config k;
+    k.voxel_size = c->voxel_size; k.voxel_size_cluster = c->voxel_size_cluster;
+    k.max_range = c->max_range; k.min_range = c->min_range;
+    k.max_points_per_voxel = c->max_points_per_voxel;
+    k.min_motion_th = c->min_motion_th; k.initial_threshold = c->initial_threshold;
+    k.model_deviation_trans = c->model_deviation_trans; k.model_deviation_rot = c->model_deviation_rot;
+    k.inlier_rate_th = c->inlier_rate_th; k.deskew = c->deskew != 0;
+    k.relocalization_enable = c->relocalization_enable != 0;
+    k.deltaA = c->deltaA; k.deltaR = c->deltaR; k.deltaP = c->deltaP;
+    k.edge_dis_th = c->edge_dis_th; k.subgraph_edge_th = c->subgraph_edge_th;
+    k.subinterval = c->subinterval; k.graph_node_dimension = c->graph_node_dimension;
+    k.nn_vehicle = c->nn_vehicle; k.nn_pole = c->nn_pole;
+    k.max_local_graph_map_range = c->max_local_graph_map_range;
+    k.order_mode = c->order_mode; k.prune_mode = c->prune_mode;
+    auto *h = new SlamHandle(k);
+    h->slam.do_graph = c->enable_graph != 0;
+    return h;
+}
+void sgo_slam_destroy(void *h) { delete (SlamHandle *)h; }
+// counts8: [n_in, n_cluster, n_ds, n_src, n_boxes, icp_iters, map_voxels, corr_total]; stage_ms[8]
+void sgo_slam_process(void *hh, const double *xyz, const int32_t *label, int n, const double *ts,
+                      int is_kitti, double *pose7, double *sigma, int64_t *counts8, double *stage_ms,
+                      int64_t *candidates) {
+    auto *h = (SlamHandle *)hh;
+    std::vector<int> lab(label, label + n);
+    std::vector<double> t;
+    if (ts) t.assign(ts, ts + n);
+    h->last = h->slam.mainProcess(vec3_in(xyz, n), lab, t, is_kitti != 0);
+    const ScanOutput &o = h->last;
+    if (pose7) pose_out(o.pose, pose7);
+    if (sigma) *sigma = o.sigma;
+    if (counts8) {
+        counts8[0] = (int64_t)o.cropped.size(); counts8[1] = (int64_t)o.cluster_cloud.size();
+        counts8[2] = (int64_t)o.frame_downsample.size(); counts8[3] = (int64_t)o.source.size();
+        counts8[4] = (int64_t)o.boxes.size(); counts8[5] = o.icp.iterations;
+        counts8[6] = (int64_t)h->slam.local_map_.map_.size(); counts8[7] = o.icp.correspondences;
+    }
+    if (stage_ms) std::memcpy(stage_ms, o.stage_ms, sizeof(double) * 8);
+    if (candidates) *candidates = o.icp.candidates;
+}
+// which: 0 cropped, 1 cluster cloud, 2 frame_downsample, 3 source
+int sgo_slam_get_cloud(void *hh, int which, double *xyz, int32_t *label, int cap) {
+    auto *h = (SlamHandle *)hh;
+    const Cloud *c = which == 0 ? &h->last.cropped : which == 1 ? &h->last.cluster_cloud : which == 2 ? &h->last.frame_downsample : &h->last.source;
+    const int n = (int)c->size() < cap ? (int)c->size() : cap;
+    for (int i = 0; i < n; ++i) {
+        if (xyz) { xyz[3 * i] = c->p[(size_t)i].x; xyz[3 * i + 1] = c->p[(size_t)i].y; xyz[3 * i + 2] = c->p[(size_t)i].z; }
+        if (label) label[i] = c->l[(size_t)i];
+    }
+    return (int)c->size();
+}
+int sgo_slam_get_boxes(void *hh, double *boxes, int cap) {
+    auto *h = (SlamHandle *)hh;
+    const auto &bb = h->last.boxes;
+    for (int i = 0; i < (int)bb.size() && i < cap; ++i) {
+        double *o = boxes + 8 * (size_t)i;
+        o[0] = bb[(size_t)i].center.x; o[1] = bb[(size_t)i].center.y; o[2] = bb[(size_t)i].center.z;
+        o[3] = bb[(size_t)i].dimension.x; o[4] = bb[(size_t)i].dimension.y; o[5] = bb[(size_t)i].dimension.z;
+        o[6] = bb[(size_t)i].label; o[7] = bb[(size_t)i].points_num;
+    }
+    return (int)bb.size();
+}
+void *sgo_slam_map(void *hh) { return &((SlamHandle *)hh)->slam.local_map_; }
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+// Synthetic LiDAR scan generator (harness, host-only): analytic ray casting of a "ring road" street
+// scene, producing KITTI-layout scans (float32 x,y,z,intensity + uint32 SemanticKITTI raw label)
+// as SURVEY.md section 8(d) specifies for config S: 64 beams (+2.0 .. -24.8 deg) x 1875 columns
+// = 120 000 rays, 20 static classes, Gaussian range noise sigma = 0.02 m from a counter-based
+// Philox4x32-10 stream (seed 20251031, stream = frame index), ego motion 1.0 m / 0.004 rad per
+// frame.  A constant yaw rate means the vehicle drives a circle of radius 250 m, so the street is
+// laid out in ring coordinates (arc position phi around the circle centre, lateral offset d).
+// This is data generation only: it implements nothing of the reference and is used by tests and
+// bench.py to feed both the HIP path and the CPU oracle the same input.
+#include <omp.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kR = 250.0;           // ring-road radius = 1 m / 0.004 rad
+constexpr double kGroundZ = -1.73;     // sensor height above ground
+constexpr double kMaxRay = 130.0;
+constexpr int kRampFrames = 10;        // the vehicle accelerates 0 -> 1 m/frame over the first frames
+
+// arc length travelled at frame k: quadratic ramp-up, then exactly 1.0 m (= 0.004 rad) per frame
+inline double arc_of_frame(int k) {
+    if (k < kRampFrames) return 0.5 * (double)k * (double)k / kRampFrames;
+    return 0.5 * kRampFrames + (double)(k - kRampFrames);
+}
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------
+struct Philox {
+    static inline void round(uint32_t c[4], const uint32_t k[2]) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    static inline void gen(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t out[4]) {
+        uint32_t c[4] = {c0, c1, c2, 0};
+        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        for (int i = 0; i < 10; ++i) {
+            round(c, k);
+            k[0] += 0x9E3779B9u;
+            k[1] += 0xBB67AE85u;
+        }
+        std::memcpy(out, c, sizeof(c));
+    }
+};
+inline double u01(uint32_t a) { return ((double)a + 0.5) / 4294967296.0; }
+inline uint32_t hash32(uint32_t a, uint32_t b) {
+    uint32_t o[4];
+    Philox::gen(0x5EEDu, a, b, 0x1234u, o);
+    return o[0];
+}
+inline double hrand(uint32_t kind, int idx, uint32_t salt) { return u01(hash32(kind * 7919u + salt, (uint32_t)idx)); }
+
+struct Obj {
+    int type;  // 0 vertical cylinder, 1 sphere, 2 oriented box
+    double cx, cy, cz;
+    double r;           // cylinder/sphere radius, bounding radius for box
+    double z0, z1;      // cylinder z range
+    double hx, hy, hz;  // box half extents
+    double cs, sn;      // box yaw
+    int label;
+};
+
+struct Scene {
+    std::vector<Obj> objs;
+};
+
+inline void ring_to_world(double phi, double d, double *x, double *y) {
+    // path point: (R sin phi, R - R cos phi); left normal (towards centre) = (-sin phi, cos phi)
+    const double rho = kR - d;
+    *x = rho * std::sin(phi);
+    *y = kR - rho * std::cos(phi);
+}
+
+void add_box(Scene &s, double phi, double d, double zc, double len, double wid, double hgt, int label) {
+    Obj o{};
+    o.type = 2;
+    ring_to_world(phi, d, &o.cx, &o.cy);
+    o.cz = zc;
+    o.hx = len / 2; o.hy = wid / 2; o.hz = hgt / 2;
+    o.cs = std::cos(phi); o.sn = std::sin(phi);  // box x-axis along the tangent
+    o.r = std::sqrt(o.hx * o.hx + o.hy * o.hy);
+    o.label = label;
+    s.objs.push_back(o);
+}
+void add_cyl(Scene &s, double phi, double d, double r, double z0, double z1, int label) {
+    Obj o{};
+    o.type = 0;
+    ring_to_world(phi, d, &o.cx, &o.cy);
+    o.r = r; o.z0 = z0; o.z1 = z1; o.label = label;
+    s.objs.push_back(o);
+}
+void add_sph(Scene &s, double phi, double d, double zc, double r, int label) {
+    Obj o{};
+    o.type = 1;
+    ring_to_world(phi, d, &o.cx, &o.cy);
+    o.cz = zc; o.r = r; o.label = label;
+    s.objs.push_back(o);
+}
+
+// objects whose arc position lies within +-reach metres of the vehicle
+void build_scene(Scene &s, double phi0, double reach) {
+    s.objs.clear();
+    const double dphi = reach / kR;
+    auto span = [&](int count, int *lo, int *hi) {
+        const double step = 2 * kPi / count;
+        *lo = (int)std::floor((phi0 - dphi) / step);
+        *hi = (int)std::ceil((phi0 + dphi) / step);
+    };
+    int lo, hi;
+    // parked vehicles every ~6.5 m on both sides (242 slots): car / truck / other-vehicle / empty
+    span(242, &lo, &hi);
+    for (int i = lo; i <= hi; ++i)
+        for (int side = 0; side < 2; ++side) {
+            const int id = i * 2 + side;
+            const double u = hrand(1, id, 0);
+            const double phi = (i + 0.1 * hrand(1, id, 1)) * (2 * kPi / 242);
+            const double sg = side ? -1.0 : 1.0;
+            if (u < 0.26) add_box(s, phi, sg * 3.05, kGroundZ + 0.78, 4.5, 1.8, 1.5, 1);
+            else if (u < 0.29) add_box(s, phi, sg * 3.2, kGroundZ + 1.65, 6.2, 2.4, 3.2, 4);
+            else if (u < 0.32) add_box(s, phi, sg * 3.1, kGroundZ + 1.25, 5.6, 2.1, 2.4, 5);
+            else if (u < 0.35) add_box(s, phi, sg * 3.4, kGroundZ + 0.6, 2.0, 0.7, 1.2, 3);  // motorcycle
+        }
+    // trunks (16) with vegetation crowns, every ~12 m, both sides
+    span(131, &lo, &hi);
+    for (int i = lo; i <= hi; ++i)
+        for (int side = 0; side < 2; ++side) {
+            const int id = i * 2 + side;
+            const double phi = (i + 0.2 * hrand(2, id, 1)) * (2 * kPi / 131);
+            const double sg = side ? -1.0 : 1.0;
+            const double h = 3.0 + 2.0 * hrand(2, id, 2);
+            const double r = 0.2 + 0.1 * hrand(2, id, 3);
+            add_cyl(s, phi, sg * 6.5, r, kGroundZ, kGroundZ + h, 16);
+            add_sph(s, phi, sg * 6.5, kGroundZ + h + 1.0, 1.6 + 0.6 * hrand(2, id, 4), 15);
+        }
+    // poles (18), every ~12 m offset by half a period; every third carries a traffic sign (19)
+    for (int i = lo; i <= hi; ++i)
+        for (int side = 0; side < 2; ++side) {
+            const int id = i * 2 + side;
+            const double phi = (i + 0.5 + 0.1 * hrand(3, id, 1)) * (2 * kPi / 131);
+            const double sg = side ? -1.0 : 1.0;
+            const double h = 6.0 + 2.0 * hrand(3, id, 2);
+            add_cyl(s, phi, sg * 5.2, 0.15, kGroundZ, kGroundZ + h, 18);
+            if (((i % 3) + 3) % 3 == 0) add_box(s, phi, sg * 5.2, kGroundZ + 2.6, 0.1, 0.9, 0.9, 19);
+        }
+    // vegetation blobs (15) every ~13 m at d = +-9.5
+    span(121, &lo, &hi);
+    for (int i = lo; i <= hi; ++i)
+        for (int side = 0; side < 2; ++side) {
+            const int id = i * 2 + side;
+            const double phi = (i + 0.3 * hrand(4, id, 1)) * (2 * kPi / 121);
+            const double sg = side ? -1.0 : 1.0;
+            add_sph(s, phi, sg * (9.5 + 0.8 * hrand(4, id, 2)), kGroundZ + 1.0 + 1.2 * hrand(4, id, 3),
+                    1.2 + 0.8 * hrand(4, id, 4), 15);
+        }
+    // buildings (13): boxes of varying length / setback / height every ~16 m with gaps between them,
+    // plus a porch-like protrusion on most of them: gives the street along-track structure
+    span(98, &lo, &hi);
+    for (int i = lo; i <= hi; ++i)
+        for (int side = 0; side < 2; ++side) {
+            const int id = i * 2 + side;
+            const double step = 2 * kPi / 98;
+            const double sg = side ? -1.0 : 1.0;
+            const double len = 8.0 + 6.0 * hrand(6, id, 1);
+            const double hgt = 5.0 + 7.0 * hrand(6, id, 2);
+            const double front = 14.0 + 4.0 * hrand(6, id, 3);
+            const double phi = (i + 0.15 * hrand(6, id, 4)) * step;
+            add_box(s, phi, sg * (front + 4.0), kGroundZ + hgt / 2, len, 8.0, hgt, 13);
+            if (hrand(6, id, 5) < 0.7) {
+                const double pl = 1.5 + 2.0 * hrand(6, id, 6);
+                const double off = (hrand(6, id, 7) - 0.5) * (len - pl) / kR;
+                add_box(s, phi + off, sg * (front - 0.75), kGroundZ + 1.5, pl, 1.5, 3.0, 13);
+            }
+        }
+    // pedestrians / cyclists / small objects on the sidewalks, every ~17 m
+    span(92, &lo, &hi);
+    for (int i = lo; i <= hi; ++i)
+        for (int side = 0; side < 2; ++side) {
+            const int id = i * 2 + side;
+            const double u = hrand(5, id, 0);
+            const double phi = (i + 0.5 * hrand(5, id, 1)) * (2 * kPi / 92);
+            const double sg = side ? -1.0 : 1.0;
+            if (u < 0.25) add_cyl(s, phi, sg * 4.8, 0.25, kGroundZ, kGroundZ + 1.75, 6);            // person
+            else if (u < 0.40) add_box(s, phi, sg * 4.6, kGroundZ + 0.55, 1.8, 0.5, 1.1, 2);        // bicycle
+            else if (u < 0.50) add_box(s, phi, sg * 3.7, kGroundZ + 0.9, 1.8, 0.6, 1.8, 7);         // bicyclist
+            else if (u < 0.58) add_box(s, phi, sg * 3.6, kGroundZ + 0.85, 2.1, 0.8, 1.7, 8);        // motorcyclist
+            else if (u < 0.70) add_box(s, phi, sg * 5.6, kGroundZ + 0.5, 0.8, 0.8, 1.0, 0);         // unlabeled object
+        }
+}
+
+struct Hit {
+    double t;
+    int label;
+};
+
+inline double wrap_pi(double a) {
+    while (a > kPi) a -= 2 * kPi;
+    while (a < -kPi) a += 2 * kPi;
+    return a;
+}
+inline double ring_phi(double x, double y) { return std::atan2(x, -(y - kR)); }
+
+inline int ground_label(double x, double y) {
+    const double rho = std::sqrt(x * x + (y - kR) * (y - kR));
+    const double d = std::fabs(kR - rho);
+    const double s = ring_phi(x, y) * kR;
+    const double m50 = s - 50.0 * std::floor(s / 50.0);
+    if (d < 4.0) return 9;                       // road
+    if (d < 6.0) return (m50 < 10.0) ? 10 : 11;  // parking bays / sidewalk
+    if (d < 25.0) return 17;                     // terrain
+    return 12;                                   // other-ground
+}
+
+// vertical ring wall rho = rw about (0,R): mask(phi) decides presence
+template <class Mask>
+inline void hit_ring(double ox, double oy, double oz, double dx, double dy, double dz, double rw,
+                     double z0, double z1, int label, Mask mask, Hit &best) {
+    const double px = ox, py = oy - kR;
+    const double a = dx * dx + dy * dy;
+    if (a < 1e-12) return;
+    const double b = px * dx + py * dy;
+    const double c = px * px + py * py - rw * rw;
+    const double disc = b * b - a * c;
+    if (disc < 0) return;
+    const double sq = std::sqrt(disc);
+    const double ts[2] = {(-b - sq) / a, (-b + sq) / a};
+    for (int k = 0; k < 2; ++k) {
+        const double t = ts[k];
+        if (t <= 0.05 || t >= best.t) continue;
+        const double z = oz + t * dz;
+        if (z < z0 || z > z1) continue;
+        const double hx = ox + t * dx, hy = oy + t * dy;
+        if (!mask(ring_phi(hx, hy) * kR)) continue;
+        best.t = t;
+        best.label = label;
+        return;
+    }
+}
+
+inline void hit_obj(const Obj &o, double ox, double oy, double oz, double dx, double dy, double dz, Hit &best) {
+    if (o.type == 0) {
+        const double px = ox - o.cx, py = oy - o.cy;
+        const double a = dx * dx + dy * dy;
+        if (a < 1e-12) return;
+        const double b = px * dx + py * dy;
+        const double c = px * px + py * py - o.r * o.r;
+        const double disc = b * b - a * c;
+        if (disc < 0) return;
+        const double t = (-b - std::sqrt(disc)) / a;
+        if (t <= 0.05 || t >= best.t) return;
+        const double z = oz + t * dz;
+        if (z < o.z0 || z > o.z1) return;
+        best.t = t;
+        best.label = o.label;
+    } else if (o.type == 1) {
+        const double px = ox - o.cx, py = oy - o.cy, pz = oz - o.cz;
+        const double b = px * dx + py * dy + pz * dz;
+        const double c = px * px + py * py + pz * pz - o.r * o.r;
+        const double disc = b * b - c;
+        if (disc < 0) return;
+        const double t = -b - std::sqrt(disc);
+        if (t <= 0.05 || t >= best.t) return;
+        best.t = t;
+        best.label = o.label;
+    } else {
+        const double rx = ox - o.cx, ry = oy - o.cy, rz = oz - o.cz;
+        const double lx = o.cs * rx + o.sn * ry, ly = -o.sn * rx + o.cs * ry;
+        const double ex = o.cs * dx + o.sn * dy, ey = -o.sn * dx + o.cs * dy;
+        double tmin = 0.05, tmax = best.t;
+        const double lo[3] = {lx, ly, rz}, di[3] = {ex, ey, dz}, h[3] = {o.hx, o.hy, o.hz};
+        for (int k = 0; k < 3; ++k) {
+            if (std::fabs(di[k]) < 1e-12) {
+                if (std::fabs(lo[k]) > h[k]) return;
+            } else {
+                double t1 = (-h[k] - lo[k]) / di[k], t2 = (h[k] - lo[k]) / di[k];
+                if (t1 > t2) { const double tt = t1; t1 = t2; t2 = tt; }
+                if (t1 > tmin) tmin = t1;
+                if (t2 < tmax) tmax = t2;
+                if (tmin > tmax) return;
+            }
+        }
+        if (tmin <= 0.05 || tmin >= best.t) return;
+        best.t = tmin;
+        best.label = o.label;
+    }
+}
+
+const uint32_t kRawLabel[20] = {0, 10, 11, 15, 18, 20, 30, 31, 32, 40, 44, 48, 49, 50, 51, 70, 71, 72, 80, 81};
+
+}  // namespace
+
+extern "C" {
+
+// ground-truth sensor pose of frame k: [qx,qy,qz,qw,tx,ty,tz]
+void sgs_synth_pose(int frame, double *pose7) {
+    const double phi = arc_of_frame(frame) / kR;
+    pose7[0] = 0; pose7[1] = 0; pose7[2] = std::sin(phi / 2); pose7[3] = std::cos(phi / 2);
+    pose7[4] = kR * std::sin(phi); pose7[5] = kR - kR * std::cos(phi); pose7[6] = 0;
+}
+
+// Generates frame `frame`.  beams x cols rays, elevations linearly from elev_top_deg (beam 0) to
+// elev_bottom_deg, point index = col*beams + beam.  xyzi: n*4 float32, raw_label: n uint32
+// (SemanticKITTI raw ids, lower 16 bits), mapped_label (optional): n int32 in 0..19.
+// Rays that hit nothing (or beyond 130 m) are returned as (0,0,0).  Returns n.
+int sgs_synth_scan(int frame, int beams, int cols, double elev_top_deg, double elev_bottom_deg,
+                   double noise_sigma, uint64_t seed, float *xyzi, uint32_t *raw_label,
+                   int32_t *mapped_label) {
+    const double phi0 = arc_of_frame(frame) / kR;
+    const double ox = kR * std::sin(phi0), oy = kR - kR * std::cos(phi0), oz = 0.0;
+    Scene scene;
+    build_scene(scene, phi0, 135.0);
+    const int nobj = (int)scene.objs.size();
+    // per-object bearing interval (world frame) for column culling
+    std::vector<double> bear((size_t)nobj), half((size_t)nobj);
+    for (int j = 0; j < nobj; ++j) {
+        const Obj &o = scene.objs[(size_t)j];
+        const double rx = o.cx - ox, ry = o.cy - oy;
+        const double dist = std::sqrt(rx * rx + ry * ry);
+        bear[(size_t)j] = std::atan2(ry, rx);
+        half[(size_t)j] = (dist <= o.r * 1.05 + 0.05) ? kPi : std::asin(std::fmin(1.0, (o.r * 1.05 + 0.05) / dist));
+    }
+    auto wall2_mask = [](double s) { const double m = s - 33.0 * std::floor(s / 33.0); return m > 5.0; };
+    auto fence_mask = [](double s) { const double m = s - 20.0 * std::floor(s / 20.0); return m < 12.0; };
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int c = 0; c < cols; ++c) {
+        const double az_s = -2.0 * kPi * c / cols;  // spinning clockwise like an HDL-64
+        const double az_w = az_s + phi0;
+        std::vector<int> cand;
+        for (int j = 0; j < nobj; ++j)
+            if (std::fabs(wrap_pi(az_w - bear[(size_t)j])) <= half[(size_t)j]) cand.push_back(j);
+        for (int b = 0; b < beams; ++b) {
+            const double el = (beams > 1 ? elev_top_deg + (elev_bottom_deg - elev_top_deg) * b / (beams - 1) : elev_top_deg) * kPi / 180.0;
+            const double ce = std::cos(el), se = std::sin(el);
+            const double dx = ce * std::cos(az_w), dy = ce * std::sin(az_w), dz = se;
+            Hit best{kMaxRay, -1};
+            if (dz < -1e-9) {
+                const double t = (kGroundZ - oz) / dz;
+                if (t > 0.05 && t < best.t) { best.t = t; best.label = -2; }
+            }
+            hit_ring(ox, oy, oz, dx, dy, dz, kR - 34.0, kGroundZ, kGroundZ + 14.0, 13, wall2_mask, best);
+            hit_ring(ox, oy, oz, dx, dy, dz, kR + 34.0, kGroundZ, kGroundZ + 14.0, 13, wall2_mask, best);
+            hit_ring(ox, oy, oz, dx, dy, dz, kR - 7.5, kGroundZ, kGroundZ + 1.3, 14, fence_mask, best);
+            hit_ring(ox, oy, oz, dx, dy, dz, kR + 7.5, kGroundZ, kGroundZ + 1.3, 14, fence_mask, best);
+            for (int j : cand) hit_obj(scene.objs[(size_t)j], ox, oy, oz, dx, dy, dz, best);
+            const size_t i = (size_t)c * beams + b;
+            float *o = xyzi + 4 * i;
+            if (best.label == -1) {
+                o[0] = o[1] = o[2] = o[3] = 0.f;
+                if (raw_label) raw_label[i] = 0;
+                if (mapped_label) mapped_label[i] = 0;
+                continue;
+            }
+            int label = best.label;
+            if (label == -2) label = ground_label(ox + best.t * dx, oy + best.t * dy);
+            uint32_t rnd[4];
+            Philox::gen(seed, (uint32_t)i, (uint32_t)frame, 0, rnd);
+            const double g = std::sqrt(-2.0 * std::log(u01(rnd[0]))) * std::cos(2 * kPi * u01(rnd[1]));
+            const double t = best.t + noise_sigma * g;
+            // back to the sensor frame: direction in sensor frame has azimuth az_s
+            o[0] = (float)(t * ce * std::cos(az_s));
+            o[1] = (float)(t * ce * std::sin(az_s));
+            o[2] = (float)(t * se);
+            o[3] = (float)(0.1 + 0.04 * label);
+            if (raw_label) raw_label[i] = kRawLabel[label];
+            if (mapped_label) mapped_label[i] = label;
+        }
+    }
+    return beams * cols;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+"""Synthetic HDL-64-shaped scan generator (harness; ctypes over lib/libsgs_synth.so).
+
+Shapes follow SURVEY.md section 8(d): config S = 64 beams x 1875 columns = 120 000 rays,
+elevations +2.0 .. -24.8 deg, range noise sigma 0.02 m, seed 20251031, 1 m + 0.004 rad per frame.
+The label remap mirrors the reference loader (ros/ros1/InsUtils.hpp:50-85, :526).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_LIB = None
+SEED = 20251031
+
+# ros/ros1/InsUtils.hpp:50-85  SemanticKITTI raw id -> 0..25
+LABEL_MAP = {
+    0: 0, 1: 0, 10: 1, 11: 2, 13: 5, 15: 3, 16: 5, 18: 4, 20: 5, 30: 6, 31: 7, 32: 8, 40: 9, 44: 10,
+    48: 11, 49: 12, 50: 13, 51: 14, 52: 0, 60: 9, 70: 15, 71: 16, 72: 17, 80: 18, 81: 19, 99: 0,
+    252: 20, 253: 21, 254: 22, 255: 23, 256: 24, 257: 24, 258: 25, 259: 24,
+}
+
+SHAPES = {
+    # name: (beams, cols, elev_top_deg, elev_bottom_deg)
+    "hdl64": (64, 1875, 2.0, -24.8),       # config S, 120 000 rays
+    "os1_64": (64, 1024, 16.6, -16.6),     # config M, 65 536 rays
+    "dense128": (128, 8192, 2.0, -24.8),   # config D, 1 048 576 rays
+    "mini": (16, 450, 2.0, -24.8),         # CPU-test size, 7 200 rays
+    "small": (32, 900, 2.0, -24.8),        # 28 800 rays
+}
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsgs_synth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make synth` (or __graft_entry__.build())")
+        lib = ctypes.CDLL(path)
+        lib.sgs_synth_scan.restype = ctypes.c_int
+        lib.sgs_synth_scan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_double, ctypes.c_uint64,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.sgs_synth_pose.restype = None
+        lib.sgs_synth_pose.argtypes = [ctypes.c_int, ctypes.c_void_p]
+        _LIB = lib
+    return _LIB
+
+
+def remap_labels(raw):
+    """uint32 raw SemanticKITTI labels -> int32 0..25 (unknown ids -> 0, like label_map[...])."""
+    lut = np.zeros(65536, dtype=np.int32)
+    for k, v in LABEL_MAP.items():
+        lut[k] = v
+    return lut[(np.asarray(raw, dtype=np.uint32) & 0xFFFF).astype(np.int64)]
+
+
+def scan(frame, shape="hdl64", noise_sigma=0.02, seed=SEED):
+    """Returns (xyzi float32 [n,4], raw_label uint32 [n], label int32 [n])."""
+    beams, cols, top, bottom = SHAPES[shape] if isinstance(shape, str) else shape
+    n = beams * cols
+    xyzi = np.empty((n, 4), dtype=np.float32)
+    raw = np.empty(n, dtype=np.uint32)
+    lab = np.empty(n, dtype=np.int32)
+    _lib().sgs_synth_scan(int(frame), beams, cols, float(top), float(bottom), float(noise_sigma),
+                          int(seed), xyzi.ctypes.data, raw.ctypes.data, lab.ctypes.data)
+    return xyzi, raw, lab
+
+
+def gt_pose(frame):
+    """Ground-truth sensor pose [qx,qy,qz,qw,tx,ty,tz] of a frame."""
+    p = np.empty(7, dtype=np.float64)
+    _lib().sgs_synth_pose(int(frame), p.ctypes.data)
+    return p
+
+
+def mulran_timestamps(n, beams=64, cols=1024):
+    """ros/ros1/semSLAM.cpp:143-151: timestamps floor(i/64)/1024 for Ouster-style scans."""
+    return (np.floor(np.arange(n) / beams) / cols).astype(np.float64)
