@@ -7,7 +7,7 @@ CXX ?= g++
 PKG := sg-slam_amd
 HIP_SRCS := $(wildcard $(PKG)/csrc/*.hip)
 HIP_HDRS := $(wildcard $(PKG)/csrc/*.h $(PKG)/csrc/*.hpp include/*.h)
-HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/csrc -Wall -Wno-unused-result
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/csrc -Wall -Wno-unused-result -Wno-unused-value
 
 all: oracle synth hip
 oracle:
@@ -17,9 +17,13 @@ hip: $(PKG)/lib/libsgs_hip.so
 $(PKG)/lib/libsgs_synth.so: $(PKG)/csrc/synth.cpp
 	@mkdir -p $(PKG)/lib
 	$(CXX) -O2 -std=c++17 -fPIC -fopenmp -shared -o $@ $<
-$(PKG)/lib/libsgs_hip.so: $(HIP_SRCS) $(HIP_HDRS)
+HIP_OBJS := $(patsubst $(PKG)/csrc/%.hip,build/%.o,$(HIP_SRCS))
+build/%.o: $(PKG)/csrc/%.hip $(HIP_HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(PKG)/lib/libsgs_hip.so: $(HIP_OBJS)
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
 clean:
 	rm -f $(PKG)/lib/*.so oracle/liboracle.so
 .PHONY: all oracle synth hip clean

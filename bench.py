@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: scans/sec of the per-scan odometry hot path (BASELINE.json metric) on
+synthetic HDL-64-shaped 120 000-point scans (configs[1]), one scan stream per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one scan through sgs_process_scan_f32_dev (crop, 3 voxel downsamples, device-resident
+Gauss-Newton ICP against the GPU voxel map, map update + prune, instance clustering + graph), input
+scan already resident in HBM, pose/counters back on the host when the step returns.
+Rank 0 prints ONE JSON line (contract fields + `roofline` + `cpu_baseline`).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--shape", default="hdl64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip instance clustering + graph (diagnostic only)")
+    ap.add_argument("--cpu-max-scans", type=int, default=120)
+    args = ap.parse_args()
+
+    import torch
+    from sg_slam_amd import api, synth
+    from sg_slam_amd.runner import Dist, timed_steps
+
+    dist = Dist()
+    rank, local_rank, world = dist.rank, dist.local_rank, dist.world
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    W, K = args.warmup, args.steps
+    total = W + K
+    # every rank drives its own, independent scan stream (different noise seed per rank)
+    seed = synth.SEED + rank
+    scans_host, labels_host = [], []
+    for k in range(total):
+        xyzi, raw, lab = synth.scan(k, args.shape, seed=seed)
+        scans_host.append(xyzi)
+        labels_host.append(api.remap_labels(raw))  # loader remap (ros/ros1/InsUtils.hpp:526), outside the timed region
+    n_pts = scans_host[0].shape[0]
+    d_scans = [torch.from_numpy(s).to(dev) for s in scans_host]
+    d_labels = [torch.from_numpy(l).to(dev) for l in labels_host]
+    torch.cuda.synchronize()
+
+    def run_pass(profile):
+        cfg = api.preset("kitti", max_points=max(1 << 17, 1 << int(np.ceil(np.log2(n_pts)))), map_capacity_log2=19,
+                         enable_graph=0 if args.no_graph else 1)
+        ctx = api.Context(cfg, device=local_rank)
+        ctx.set_profiling(profile)
+        res = api.SgsScanResult()
+        poses = np.zeros((total, 7))
+        counts = np.zeros((total, 6), dtype=np.int64)
+
+        def step(i):
+            ctx.process_scan_dev(d_scans[i].data_ptr(), d_labels[i].data_ptr(), n_pts, None, "", res)
+            poses[i] = res.pose[:]
+            counts[i] = (res.n_in, res.n_cluster, res.n_ds, res.n_src, res.icp_iterations, res.map_voxels)
+
+        for i in range(W):
+            step(i)
+        ctx.reset_stats()
+        elapsed, job_steps = timed_steps(dist, lambda i: step(W + i), K, sync_fn=torch.cuda.synchronize)
+        st = ctx.stats()
+        ctx.close()
+        return elapsed, job_steps, st, poses, counts
+
+    elapsed, job_steps, _, poses, counts = run_pass(profile=False)
+    # second, identical pass with HIP events around every launch of the dominant kernel (events are
+    # recorded on the context's own stream); kept out of the headline timing because the event pairs
+    # add host work per Gauss-Newton iteration.
+    elapsed_p, _, st, poses_p, _ = run_pass(profile=True)
+
+    value = job_steps / elapsed
+    tc = counts[W:]
+    launches = max(1, st.icp_kernel_launches)
+    # algorithmic bytes of the fused correspondence + linear-system kernel (SURVEY.md 8d B_iter):
+    # per query 16 B point + 27 slot probes x 16 B + 16 B per resident candidate, + 27 x 8 B result
+    bytes_total = st.icp_queries_total * (16 + 27 * 16) + 16 * st.icp_candidates_total + launches * 27 * 8
+    kern_s = st.icp_kernel_ms_total * 1e-3
+    achieved = bytes_total / kern_s / 1e9 if kern_s > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": "icp_accumulate_kernel (27-neighbour correspondences + JtJ/Jtr reduction)",
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": None,
+        "launches": int(st.icp_kernel_launches), "avg_launch_us": round(1e3 * st.icp_kernel_ms_total / launches, 3),
+        "algorithmic_bytes_per_launch": int(bytes_total / launches),
+        "profiled_pass_ms_per_step": round(1e3 * elapsed_p / K, 4),
+        "stage_ms_per_scan": {k: round(st.stage_ms[i] / max(1, st.scans), 4)
+                              for i, k in enumerate(["preprocess", "downsample", "icp", "map_update", "cluster_graph"])},
+    }
+    out = {
+        "metric": "scans/sec (120k-pt HDL-64 scan-to-map ICP)", "value": round(value, 2), "unit": "scans/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 keys/accumulation + f32 candidate distances",
+        "data": "synthetic",
+        "config": {"workload": "synthetic HDL-64-shaped scans (64x1875 = 120000 rays, 20 classes), voxel 1.0 m, max 20 pts/voxel, "
+                               "frame-by-frame odometry + semantic graph, one scan stream per GPU (BASELINE.json configs[1])",
+                   "shape": args.shape, "points_per_scan": int(n_pts), "preset": "kitti", "graph": not args.no_graph,
+                   "mean_n_in": float(tc[:, 0].mean()), "mean_n_cluster": float(tc[:, 1].mean()), "mean_n_ds": float(tc[:, 2].mean()),
+                   "mean_n_src": float(tc[:, 3].mean()), "mean_icp_iterations": float(tc[:, 4].mean()),
+                   "map_voxels_end": int(tc[-1, 5]),
+                   "mean_candidates_per_query": round(st.icp_candidates_total / max(1, st.icp_queries_total), 2),
+                   "mean_probes_per_query": round(st.icp_probes_total / max(1, st.icp_queries_total), 2)},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as O  # CPU baseline leg: the oracle as the timed "port" of the reference path
+        cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+        O.set_threads(cores)
+        slam = O.Slam(O.kitti_config(enable_graph=0 if args.no_graph else 1))
+        m = min(K, args.cpu_max_scans)
+        ocounts = []
+        worst_t = worst_r = 0.0
+        t_cpu = 0.0
+        for i in range(W + m):
+            xyz = scans_host[i][:, :3].astype(np.float64)  # loader widening, not timed
+            t0 = time.perf_counter()
+            r = slam.process(xyz, labels_host[i])
+            dt = time.perf_counter() - t0
+            if i >= W:
+                t_cpu += dt
+            d = O.se3_mul(O.se3_inv(r["pose"]), poses[i])
+            worst_t = max(worst_t, float(np.linalg.norm(d[4:])))
+            worst_r = max(worst_r, float(2 * np.arctan2(np.linalg.norm(d[:3]), abs(d[3]))))
+            ocounts.append((r["n_in"], r["n_cluster"], r["n_ds"], r["n_src"], r["iterations"], r["map_voxels"]))
+        out["cpu_baseline"] = {"value": round(m / t_cpu, 2), "unit": "scans/s", "cores": cores, "kind": "port",
+                               "sample": f"the same first {W}+{m} synthetic scans (warm-up + timed) through the oracle restatement, "
+                                         f"OpenMP where the reference uses TBB; timed scans {W}..{W + m - 1}"}
+        out["parity"] = {"scans_checked": W + m, "max_pose_diff_m": worst_t, "max_pose_diff_rad": worst_r,
+                         "counts_equal": bool(np.array_equal(np.array(ocounts), counts[:W + m]))}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,200 @@
+/*
+ * sgs.h - C ABI of the MI355X-native SG-SLAM odometry hot path (libsgs_hip.so).
+ *
+ * The reference (nubot-nudt/SG-SLAM) has no FFI/plugin boundary: the hot path is a set of plain C++
+ * functions in namespace graph_slam, called only from SemGraphSLAM::mainProcess
+ * (cpp/semgraph_slam/pipeline/SemGraphSLAM.cpp:16-121).  Each entry point below names the reference
+ * function it replaces (paths relative to cpp/semgraph_slam/).  A header-only C++ facade with the
+ * reference's own names/signatures sits on top of this ABI (sg-slam_amd/include/graph_slam_hip.hpp);
+ * INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns an int status (SGS_OK == 0, negative on error) and never throws;
+ *     sgs_last_error(ctx) returns a human-readable message for the last failure on that context.
+ *   - xyz   : n*3 doubles (std::vector<Eigen::Vector3d>::data())
+ *     xyzl  : n*4 doubles (std::vector<Eigen::Vector4d>::data(), label in lane 3)
+ *     pose7 : [qx, qy, qz, qw, tx, ty, tz]  (Sophus::SE3d unit_quaternion().coeffs() + translation())
+ *   - all pointers are HOST pointers unless the name ends in _dev.
+ *   - a context is single-threaded (externally synchronised); distinct contexts are independent and
+ *     may live on different GPUs or share one.  All calls are synchronous with respect to the host.
+ *   - outputs use caller-provided capacity + returned count: if the capacity is too small the call
+ *     fills what fits, still returns the full count, and reports SGS_ECAPACITY.
+ *   - there is NO CPU fallback: without a HIP device every compute call fails with SGS_EHIP.
+ */
+#ifndef SGS_H_
+#define SGS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGS_OK 0
+#define SGS_EINVAL (-1)    /* bad argument */
+#define SGS_EHIP (-2)      /* HIP runtime error / no device */
+#define SGS_ENOMEM (-3)    /* allocation failed */
+#define SGS_ECAPACITY (-4) /* a fixed capacity (scan size, key range, output buffer) was exceeded */
+
+/* Mirrors graph_slam::SemGraphSLAMConfig field for field (pipeline/SemGraphSLAM.hpp:25-64),
+ * followed by build-specific knobs. */
+typedef struct sgs_config {
+    uint32_t size; /* sizeof(sgs_config), for versioning */
+    int32_t max_points_per_voxel;
+    double voxel_size;
+    double voxel_size_cluster;
+    double max_range;
+    double min_range;
+    double min_motion_th;
+    double initial_threshold;
+    double model_deviation_trans;
+    double model_deviation_rot;
+    double inlier_rate_th;
+    int32_t deskew;
+    int32_t relocalization_enable; /* accepted, ignored: SURVEY.md row f1 (next) */
+    double deltaA;
+    double deltaR;
+    double deltaP;
+    double edge_dis_th;
+    double subgraph_edge_th;
+    int32_t subinterval;
+    int32_t graph_node_dimension;
+    double nearest_neighbor_vehicle_disth;
+    double nearest_neighbor_pole_disth;
+    double max_local_graph_map_range;
+    /* build-specific */
+    int32_t order_mode;        /* 0 = reference robin_map emission order, 1 = ascending first index */
+    int32_t max_points;        /* largest scan accepted (default 1<<20) */
+    int32_t map_capacity_log2; /* voxel hash slots = 1<<this (default 19); grows by rehash */
+    int32_t enable_graph;      /* run clustering + graph construction in sgs_process_scan */
+} sgs_config;
+
+typedef struct sgs_ctx sgs_ctx;
+
+/* Per-scan result of sgs_process_scan*  (what mainProcess returns/side-effects, flattened). */
+typedef struct sgs_scan_result {
+    uint32_t size;          /* sizeof(sgs_scan_result) */
+    int32_t icp_iterations; /* Gauss-Newton iterations run (0 when the map was empty) */
+    double pose[7];         /* new_pose */
+    double initial_guess[7];
+    double sigma;           /* adaptive threshold used for this scan */
+    int32_t n_raw, n_in, n_cluster, n_ds, n_src; /* cloud sizes after each stage */
+    int32_t n_boxes;        /* instance nodes found (0 when enable_graph == 0) */
+    int32_t map_voxels;     /* live voxels after the update */
+    int32_t reserved;
+    int64_t icp_correspondences; /* summed over iterations */
+    int64_t icp_candidates;      /* candidate map points examined, summed over iterations */
+} sgs_scan_result;
+
+/* Device-side timing / counters (profiling hooks; the reference only prints wall ms per frame,
+ * ros/ros1/semSLAM.cpp:194-197). */
+typedef struct sgs_stats {
+    uint32_t size;
+    uint32_t reserved;
+    int64_t scans;
+    int64_t icp_kernel_launches;   /* launches of the fused correspondence+reduction kernel */
+    double icp_kernel_ms_total;    /* HIP-event time of those launches (context stream) */
+    int64_t icp_queries_total;     /* source points processed by those launches */
+    int64_t icp_candidates_total;  /* resident candidate points examined */
+    int64_t icp_probes_total;      /* hash slots inspected by the 27-neighbour finds */
+    int64_t map_insert_cas_retries;
+    int64_t map_rehashes;
+    double stage_ms[8]; /* summed HIP-event ms: 0 preprocess, 1 downsample, 2 icp, 3 map update, 4 cluster+graph */
+} sgs_stats;
+
+/* ---- lifecycle ---- */
+void sgs_default_config(sgs_config *cfg);                 /* SemGraphSLAMConfig defaults */
+int sgs_preset(const char *name, sgs_config *cfg);        /* "kitti" | "mulran" | "apollo" | "relocalization" | "dense_128" (values from ros/launch) */
+int sgs_create(const sgs_config *cfg, int device, sgs_ctx **out);
+void sgs_destroy(sgs_ctx *ctx);
+const char *sgs_last_error(const sgs_ctx *ctx);
+int sgs_get_stats(sgs_ctx *ctx, sgs_stats *out);
+int sgs_reset_stats(sgs_ctx *ctx);
+/* Enable/disable per-kernel HIP-event timing of the ICP kernel (adds an event pair per launch). */
+int sgs_set_profiling(sgs_ctx *ctx, int enable);
+
+/* ---- frontend/Preprocessing.{hpp,cpp} ---- */
+/* PreprocessSemantic (Preprocessing.cpp:107-125): strict range + label<20 crop, order preserving. */
+int sgs_preprocess(sgs_ctx *ctx, const double *xyz, const int32_t *label, int n, double max_range,
+                   double min_range, double *out_xyz, int32_t *out_label, int out_cap, int *out_n);
+/* CorrectKITTIScan (Preprocessing.cpp:127-137). */
+int sgs_correct_kitti(sgs_ctx *ctx, const double *xyz, int n, double *out_xyz);
+/* DeSkewScan (frontend/Deskew.cpp:37-48). */
+int sgs_deskew(sgs_ctx *ctx, const double *xyz, const double *timestamps, int n,
+               const double *start_pose7, const double *finish_pose7, double *out_xyz);
+/* Voxel keys: trunc(coord / voxel_size) in fp64 (Preprocessing.cpp:77, VoxelHashMap.cpp:55-57,167). */
+int sgs_voxel_keys(sgs_ctx *ctx, const double *xyz, int n, double voxel_size, int32_t *keys_out);
+/* VoxelDownsampleSemantic (Preprocessing.cpp:70-94): first point per voxel, emitted in the
+ * reference's tsl::robin_map iteration order (cfg.order_mode 0).  out_index (optional) receives the
+ * input index of every emitted point. */
+int sgs_voxel_downsample(sgs_ctx *ctx, const double *xyz, const int32_t *label, int n,
+                         double voxel_size, double *out_xyz, int32_t *out_label, int32_t *out_index,
+                         int out_cap, int *out_n);
+
+/* ---- frontend/VoxelHashMap.{hpp,cpp}: the context owns one local map ---- */
+int sgs_map_clear(sgs_ctx *ctx);                                     /* VoxelHashMap::Clear  (hpp:71) */
+int sgs_map_empty(sgs_ctx *ctx, int *empty);                         /* VoxelHashMap::Empty  (hpp:72) */
+int sgs_map_add_points(sgs_ctx *ctx, const double *xyzl, int n);     /* AddPoints (cpp:164-176) */
+int sgs_map_update(sgs_ctx *ctx, const double *xyzl, int n, const double *pose7); /* Update(points,pose) (cpp:151-162) */
+int sgs_map_prune(sgs_ctx *ctx, const double *origin3);              /* RemovePointsFarFromLocation (cpp:178-186) */
+int sgs_map_size(sgs_ctx *ctx, int *voxels, int *points);
+/* Pointcloud (cpp:133-144); order = this implementation's slot order (the reference's is its
+ * robin_map bucket order; visualisation only). */
+int sgs_map_pointcloud(sgs_ctx *ctx, double *xyzl, int cap, int *n);
+/* Canonical dump for tests: voxels sorted by key; keys nv*3, counts nv, points nv*cap*4. */
+int sgs_map_dump(sgs_ctx *ctx, int max_voxels, int32_t *keys, int32_t *counts, double *points, int *n_voxels);
+/* GetCorrespondences (cpp:51-131): per query the nearest map point among the 27 neighbouring
+ * voxels, kept when closer than max_distance; query order preserved.  query_index optional. */
+int sgs_map_get_correspondences(sgs_ctx *ctx, const double *xyzl, int n, double max_distance,
+                                double *src_xyzl, double *tgt_xyzl, int32_t *query_index, int cap, int *m);
+
+/* ---- frontend/Registration.{hpp,cpp} ---- */
+/* The reduction inside AlignClouds (Registration.cpp:82-109) fused with GetCorrespondences, for
+ * already-transformed (world frame) source points: 27 unique scalars = JTJ upper triangle
+ * row-major (21) + JTr (6). */
+int sgs_build_linear_system(sgs_ctx *ctx, const double *xyzl_world, int n, double max_distance,
+                            double kernel, double *out27, int *n_correspondences);
+/* RegisterFrameSemantic (Registration.cpp:147-177) against the context's map. */
+int sgs_register_frame(sgs_ctx *ctx, const double *xyzl, int n, const double *initial_guess7,
+                       double max_correspondence_distance, double kernel, double *out_pose7,
+                       int *iterations);
+
+/* ---- frontend/SemanticCluster.{hpp,cpp}, frontend/SemGraph.{hpp,cpp} ---- */
+/* ClusterPoints (SemanticCluster.cpp:205-360).  boxes: 8 doubles each
+ * [cx,cy,cz, dx,dy,dz, label(1 vehicle/2 trunk/3 pole), points_num], in the reference's output order.
+ * point_cluster (optional, n): cluster id of every foreground point, 0 elsewhere. */
+int sgs_cluster_points(sgs_ctx *ctx, const double *xyz, const int32_t *label, int n, double deltaA,
+                       double deltaR, double deltaP, double *boxes, int box_cap, int *n_boxes,
+                       int32_t *point_cluster, int *n_foreground, int *n_background);
+/* BuildGraph (SemGraph.cpp:14-108).  desc: nb*(3*subinterval+dim) floats; edge_matrix nb*nb. */
+int sgs_build_graph(sgs_ctx *ctx, const double *boxes, int nb, double edge_dis_th, int subinterval,
+                    int graph_node_dimension, double subgraph_edge_th, float *desc,
+                    double *edge_matrix, double *eigenvalues, int32_t *edges, double *edge_value,
+                    double *edge_weights, int edge_cap, int *n_edges, int32_t *tri_counts,
+                    double *triangles, int tri_cap, int *n_triangles, int32_t *class_counts3);
+
+/* ---- pipeline/SemGraphSLAM.cpp:16-121 mainProcess ---- */
+/* One scan of odometry.  timestamps may be NULL; is_kitti applies CorrectKITTIScan (:30-33). */
+int sgs_process_scan(sgs_ctx *ctx, const double *xyz, const int32_t *label, int n,
+                     const double *timestamps, int is_kitti, sgs_scan_result *result);
+/* Same, from a KITTI-layout float32 scan (x,y,z,intensity) + labels already remapped to 0..25
+ * (the loader's float->double widening, ros/ros1/InsUtils.hpp:531, happens on the device). */
+int sgs_process_scan_f32(sgs_ctx *ctx, const float *xyzi, const int32_t *label, int n,
+                         const double *timestamps, int is_kitti, sgs_scan_result *result);
+/* Same, inputs already resident in this context's device memory (DEVICE pointers). */
+int sgs_process_scan_f32_dev(sgs_ctx *ctx, const float *xyzi_dev, const int32_t *label_dev, int n,
+                             const double *timestamps_dev, int is_kitti, sgs_scan_result *result);
+/* Clouds of the last processed scan: which = 0 cropped, 1 cluster cloud (0.2 m), 2 frame_downsample,
+ * 3 source.  xyz / label optional. */
+int sgs_get_cloud(sgs_ctx *ctx, int which, double *xyz, int32_t *label, int cap, int *n);
+/* Instance boxes of the last processed scan (layout as sgs_cluster_points). */
+int sgs_get_boxes(sgs_ctx *ctx, double *boxes, int cap, int *n);
+/* poses() (SemGraphSLAM.hpp:102): all poses so far, 7 doubles each. */
+int sgs_get_poses(sgs_ctx *ctx, double *poses7, int cap, int *n);
+/* Loader helper (ros/ros1/InsUtils.hpp:50-85,526): SemanticKITTI raw label -> 0..25. */
+int sgs_remap_labels(const uint32_t *raw, int n, int32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGS_H_ */

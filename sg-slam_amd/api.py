@@ -1,0 +1,373 @@
+"""Python host-side mirror of the reference's hot-path interface, over the C ABI of lib/libsgs_hip.so.
+
+Names follow the reference (F/Preprocessing.hpp, F/VoxelHashMap.hpp, F/Registration.hpp,
+F/SemanticCluster.hpp, F/SemGraph.hpp, P/SemGraphSLAM.hpp); every call goes through include/sgs.h.
+There is no CPU fallback: a missing library or a missing GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+c_vp = ctypes.c_void_p
+i32 = ctypes.c_int32
+i64 = ctypes.c_int64
+u32 = ctypes.c_uint32
+
+SGS_OK, SGS_EINVAL, SGS_EHIP, SGS_ENOMEM, SGS_ECAPACITY = 0, -1, -2, -3, -4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsgs_hip.so")
+
+# every symbol include/sgs.h declares
+ABI_SYMBOLS = [
+    "sgs_default_config", "sgs_preset", "sgs_create", "sgs_destroy", "sgs_last_error", "sgs_get_stats",
+    "sgs_reset_stats", "sgs_set_profiling", "sgs_preprocess", "sgs_correct_kitti", "sgs_deskew",
+    "sgs_voxel_keys", "sgs_voxel_downsample", "sgs_map_clear", "sgs_map_empty", "sgs_map_add_points",
+    "sgs_map_update", "sgs_map_prune", "sgs_map_size", "sgs_map_pointcloud", "sgs_map_dump",
+    "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_cluster_points",
+    "sgs_build_graph", "sgs_process_scan", "sgs_process_scan_f32", "sgs_process_scan_f32_dev", "sgs_get_cloud",
+    "sgs_get_boxes", "sgs_get_poses", "sgs_remap_labels",
+]
+
+
+class SgsConfig(ctypes.Structure):
+    _fields_ = [
+        ("size", u32), ("max_points_per_voxel", i32),
+        ("voxel_size", c_dbl), ("voxel_size_cluster", c_dbl), ("max_range", c_dbl), ("min_range", c_dbl),
+        ("min_motion_th", c_dbl), ("initial_threshold", c_dbl),
+        ("model_deviation_trans", c_dbl), ("model_deviation_rot", c_dbl), ("inlier_rate_th", c_dbl),
+        ("deskew", i32), ("relocalization_enable", i32),
+        ("deltaA", c_dbl), ("deltaR", c_dbl), ("deltaP", c_dbl),
+        ("edge_dis_th", c_dbl), ("subgraph_edge_th", c_dbl),
+        ("subinterval", i32), ("graph_node_dimension", i32),
+        ("nearest_neighbor_vehicle_disth", c_dbl), ("nearest_neighbor_pole_disth", c_dbl),
+        ("max_local_graph_map_range", c_dbl),
+        ("order_mode", i32), ("max_points", i32), ("map_capacity_log2", i32), ("enable_graph", i32),
+    ]
+
+
+class SgsScanResult(ctypes.Structure):
+    _fields_ = [
+        ("size", u32), ("icp_iterations", i32),
+        ("pose", c_dbl * 7), ("initial_guess", c_dbl * 7), ("sigma", c_dbl),
+        ("n_raw", i32), ("n_in", i32), ("n_cluster", i32), ("n_ds", i32), ("n_src", i32),
+        ("n_boxes", i32), ("map_voxels", i32), ("reserved", i32),
+        ("icp_correspondences", i64), ("icp_candidates", i64),
+    ]
+
+
+class SgsStats(ctypes.Structure):
+    _fields_ = [
+        ("size", u32), ("reserved", u32), ("scans", i64), ("icp_kernel_launches", i64),
+        ("icp_kernel_ms_total", c_dbl), ("icp_queries_total", i64), ("icp_candidates_total", i64),
+        ("icp_probes_total", i64), ("map_insert_cas_retries", i64), ("map_rehashes", i64),
+        ("stage_ms", c_dbl * 8),
+    ]
+
+
+class SgsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sgs error {code}: {msg}")
+        self.code = code
+
+
+_LIB = None
+
+
+def lib():
+    """Loads libsgs_hip.so (fails loudly when it has not been built)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `make hip` (or __graft_entry__.build()); there is no fallback path")
+        L = ctypes.CDLL(LIB_PATH)
+        L.sgs_last_error.restype = ctypes.c_char_p
+        L.sgs_last_error.argtypes = [c_vp]
+        L.sgs_default_config.restype = None
+        L.sgs_default_config.argtypes = [ctypes.POINTER(SgsConfig)]
+        L.sgs_preset.argtypes = [ctypes.c_char_p, ctypes.POINTER(SgsConfig)]
+        L.sgs_create.argtypes = [ctypes.POINTER(SgsConfig), c_int, ctypes.POINTER(c_vp)]
+        L.sgs_destroy.restype = None
+        L.sgs_destroy.argtypes = [c_vp]
+        L.sgs_get_stats.argtypes = [c_vp, ctypes.POINTER(SgsStats)]
+        L.sgs_reset_stats.argtypes = [c_vp]
+        L.sgs_set_profiling.argtypes = [c_vp, c_int]
+        L.sgs_preprocess.argtypes = [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp, c_int, c_vp]
+        L.sgs_correct_kitti.argtypes = [c_vp, c_vp, c_int, c_vp]
+        L.sgs_deskew.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]
+        L.sgs_voxel_keys.argtypes = [c_vp, c_vp, c_int, c_dbl, c_vp]
+        L.sgs_voxel_downsample.argtypes = [c_vp, c_vp, c_vp, c_int, c_dbl, c_vp, c_vp, c_vp, c_int, c_vp]
+        L.sgs_map_clear.argtypes = [c_vp]
+        L.sgs_map_empty.argtypes = [c_vp, c_vp]
+        L.sgs_map_add_points.argtypes = [c_vp, c_vp, c_int]
+        L.sgs_map_update.argtypes = [c_vp, c_vp, c_int, c_vp]
+        L.sgs_map_prune.argtypes = [c_vp, c_vp]
+        L.sgs_map_size.argtypes = [c_vp, c_vp, c_vp]
+        L.sgs_map_pointcloud.argtypes = [c_vp, c_vp, c_int, c_vp]
+        L.sgs_map_dump.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
+        L.sgs_map_get_correspondences.argtypes = [c_vp, c_vp, c_int, c_dbl, c_vp, c_vp, c_vp, c_int, c_vp]
+        L.sgs_build_linear_system.argtypes = [c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]
+        L.sgs_register_frame.argtypes = [c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, c_vp, c_vp]
+        L.sgs_cluster_points.argtypes = [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
+        L.sgs_build_graph.argtypes = [c_vp, c_vp, c_int, c_dbl, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]
+        L.sgs_process_scan.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_int, ctypes.POINTER(SgsScanResult)]
+        L.sgs_process_scan_f32.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_int, ctypes.POINTER(SgsScanResult)]
+        L.sgs_process_scan_f32_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_int, ctypes.POINTER(SgsScanResult)]
+        L.sgs_get_cloud.argtypes = [c_vp, c_int, c_vp, c_vp, c_int, c_vp]
+        L.sgs_get_boxes.argtypes = [c_vp, c_vp, c_int, c_vp]
+        L.sgs_get_poses.argtypes = [c_vp, c_vp, c_int, c_vp]
+        L.sgs_remap_labels.argtypes = [c_vp, c_int, c_vp]
+        _LIB = L
+    return _LIB
+
+
+def default_config(**kw):
+    c = SgsConfig()
+    lib().sgs_default_config(ctypes.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def preset(name, **kw):
+    c = SgsConfig()
+    r = lib().sgs_preset(name.encode(), ctypes.byref(c))
+    if r != SGS_OK:
+        raise SgsError(r, f"unknown preset {name}")
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def remap_labels(raw):
+    raw = np.ascontiguousarray(raw, dtype=np.uint32)
+    out = np.empty(len(raw), dtype=np.int32)
+    r = lib().sgs_remap_labels(raw.ctypes.data, len(raw), out.ctypes.data)
+    if r != SGS_OK:
+        raise SgsError(r, "sgs_remap_labels")
+    return out
+
+
+class Context:
+    """One sgs_ctx: device buffers, the local VoxelHashMap, the odometry state (SemGraphSLAM)."""
+
+    def __init__(self, cfg=None, device=0):
+        self.cfg = cfg if cfg is not None else preset("kitti")
+        self.h = c_vp()
+        r = lib().sgs_create(ctypes.byref(self.cfg), int(device), ctypes.byref(self.h))
+        if r != SGS_OK:
+            self.h = None
+            raise SgsError(r, "sgs_create failed (no HIP device, bad config or out of memory)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sgs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ck(self, r, allow_capacity=False):
+        if r == SGS_OK or (allow_capacity and r == SGS_ECAPACITY):
+            return r
+        raise SgsError(r, lib().sgs_last_error(self.h).decode())
+
+    def set_profiling(self, on):
+        self._ck(lib().sgs_set_profiling(self.h, int(bool(on))))
+
+    def stats(self):
+        s = SgsStats()
+        s.size = ctypes.sizeof(SgsStats)
+        self._ck(lib().sgs_get_stats(self.h, ctypes.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._ck(lib().sgs_reset_stats(self.h))
+
+    # ---- Preprocessing ----
+    def PreprocessSemantic(self, frame, label, max_range, min_range):
+        xyz = _f64(frame); lab = _i32(label); n = len(xyz)
+        ox = np.empty((max(n, 1), 3)); ol = np.empty(max(n, 1), dtype=np.int32); m = c_int()
+        self._ck(lib().sgs_preprocess(self.h, xyz.ctypes.data, lab.ctypes.data, n, float(max_range), float(min_range),
+                                      ox.ctypes.data, ol.ctypes.data, n, ctypes.byref(m)))
+        return ox[:m.value].copy(), ol[:m.value].copy()
+
+    def CorrectKITTIScan(self, frame):
+        xyz = _f64(frame); out = np.empty_like(xyz)
+        self._ck(lib().sgs_correct_kitti(self.h, xyz.ctypes.data, len(xyz), out.ctypes.data))
+        return out
+
+    def DeSkewScan(self, frame, timestamps, start_pose, finish_pose):
+        xyz = _f64(frame); ts = _f64(timestamps); s = _f64(start_pose); f = _f64(finish_pose); out = np.empty_like(xyz)
+        self._ck(lib().sgs_deskew(self.h, xyz.ctypes.data, ts.ctypes.data, len(xyz), s.ctypes.data, f.ctypes.data,
+                                  out.ctypes.data))
+        return out
+
+    def voxel_keys(self, frame, voxel_size):
+        xyz = _f64(frame); keys = np.empty((len(xyz), 3), dtype=np.int32)
+        self._ck(lib().sgs_voxel_keys(self.h, xyz.ctypes.data, len(xyz), float(voxel_size), keys.ctypes.data))
+        return keys
+
+    def VoxelDownsampleSemantic(self, frame, label, voxel_size):
+        xyz = _f64(frame); lab = _i32(label); n = len(xyz)
+        ox = np.empty((max(n, 1), 3)); ol = np.empty(max(n, 1), dtype=np.int32); oi = np.empty(max(n, 1), dtype=np.int32)
+        m = c_int()
+        self._ck(lib().sgs_voxel_downsample(self.h, xyz.ctypes.data, lab.ctypes.data, n, float(voxel_size), ox.ctypes.data,
+                                            ol.ctypes.data, oi.ctypes.data, n, ctypes.byref(m)))
+        return ox[:m.value].copy(), ol[:m.value].copy(), oi[:m.value].copy()
+
+    # ---- VoxelHashMap ----
+    def Clear(self):
+        self._ck(lib().sgs_map_clear(self.h))
+
+    def Empty(self):
+        e = c_int()
+        self._ck(lib().sgs_map_empty(self.h, ctypes.byref(e)))
+        return bool(e.value)
+
+    def AddPoints(self, xyzl):
+        p = _f64(xyzl)
+        self._ck(lib().sgs_map_add_points(self.h, p.ctypes.data, len(p)))
+
+    def Update(self, xyzl, pose7):
+        p = _f64(xyzl); T = _f64(pose7)
+        self._ck(lib().sgs_map_update(self.h, p.ctypes.data, len(p), T.ctypes.data))
+
+    def RemovePointsFarFromLocation(self, origin):
+        o = _f64(origin)
+        self._ck(lib().sgs_map_prune(self.h, o.ctypes.data))
+
+    def map_size(self):
+        v = c_int(); p = c_int()
+        self._ck(lib().sgs_map_size(self.h, ctypes.byref(v), ctypes.byref(p)))
+        return v.value, p.value
+
+    def Pointcloud(self):
+        _, npts = self.map_size()
+        out = np.empty((max(npts, 1), 4)); n = c_int()
+        self._ck(lib().sgs_map_pointcloud(self.h, out.ctypes.data, npts, ctypes.byref(n)))
+        return out[:n.value].copy()
+
+    def map_dump(self):
+        nv, _ = self.map_size()
+        cap = self.cfg.max_points_per_voxel
+        keys = np.empty((max(nv, 1), 3), dtype=np.int32); cnt = np.empty(max(nv, 1), dtype=np.int32)
+        pts = np.empty((max(nv, 1), cap, 4)); n = c_int()
+        self._ck(lib().sgs_map_dump(self.h, nv, keys.ctypes.data, cnt.ctypes.data, pts.ctypes.data, ctypes.byref(n)))
+        return keys[:n.value].copy(), cnt[:n.value].copy(), pts[:n.value].copy()
+
+    def GetCorrespondences(self, xyzl, max_distance):
+        p = _f64(xyzl); n = len(p)
+        src = np.empty((max(n, 1), 4)); tgt = np.empty((max(n, 1), 4)); qi = np.empty(max(n, 1), dtype=np.int32)
+        m = c_int()
+        self._ck(lib().sgs_map_get_correspondences(self.h, p.ctypes.data, n, float(max_distance), src.ctypes.data,
+                                                   tgt.ctypes.data, qi.ctypes.data, n, ctypes.byref(m)))
+        return src[:m.value].copy(), tgt[:m.value].copy(), qi[:m.value].copy()
+
+    # ---- Registration ----
+    def BuildLinearSystem(self, xyzl_world, max_distance, kernel):
+        p = _f64(xyzl_world); out = np.empty(27); m = c_int()
+        self._ck(lib().sgs_build_linear_system(self.h, p.ctypes.data, len(p), float(max_distance), float(kernel),
+                                               out.ctypes.data, ctypes.byref(m)))
+        return out, m.value
+
+    def RegisterFrameSemantic(self, xyzl, initial_guess, max_correspondence_distance, kernel):
+        p = _f64(xyzl); g = _f64(initial_guess); out = np.empty(7); it = c_int()
+        self._ck(lib().sgs_register_frame(self.h, p.ctypes.data, len(p), g.ctypes.data, float(max_correspondence_distance),
+                                          float(kernel), out.ctypes.data, ctypes.byref(it)))
+        return out, it.value
+
+    # ---- SemanticCluster / SemGraph ----
+    def ClusterPoints(self, frame, label, deltaA, deltaR, deltaP, max_boxes=4096):
+        xyz = _f64(frame); lab = _i32(label); n = len(xyz)
+        boxes = np.empty((max_boxes, 8)); pc = np.zeros(max(n, 1), dtype=np.int32)
+        nb = c_int(); nfg = c_int(); nbg = c_int()
+        self._ck(lib().sgs_cluster_points(self.h, xyz.ctypes.data, lab.ctypes.data, n, float(deltaA), float(deltaR),
+                                          float(deltaP), boxes.ctypes.data, max_boxes, ctypes.byref(nb), pc.ctypes.data,
+                                          ctypes.byref(nfg), ctypes.byref(nbg)))
+        return boxes[:nb.value].copy(), pc[:n].copy(), nfg.value, nbg.value
+
+    def BuildGraph(self, boxes, edge_dis_th=60.0, subinterval=30, graph_node_dimension=30, subgraph_edge_th=20.0):
+        boxes = _f64(boxes).reshape(-1, 8); nb = len(boxes)
+        D = 3 * subinterval + graph_node_dimension
+        desc = np.zeros((max(nb, 1), D), dtype=np.float32); em = np.zeros((max(nb, 1), max(nb, 1)))
+        ev = np.zeros(max(nb, 1)); max_e = max(nb * nb, 1)
+        edges = np.zeros((max_e, 2), dtype=np.int32); evalue = np.zeros(max_e); ew = np.zeros(max_e)
+        tc = np.zeros(max(nb, 1), dtype=np.int32); max_tri = max(nb * nb * nb, 1)
+        tri = np.zeros((max_tri, 3)); c3 = np.zeros(3, dtype=np.int32); ne = c_int(); nt = c_int()
+        self._ck(lib().sgs_build_graph(self.h, boxes.ctypes.data, nb, float(edge_dis_th), int(subinterval),
+                                       int(graph_node_dimension), float(subgraph_edge_th), desc.ctypes.data, em.ctypes.data,
+                                       ev.ctypes.data, edges.ctypes.data, evalue.ctypes.data, ew.ctypes.data, max_e,
+                                       ctypes.byref(ne), tc.ctypes.data, tri.ctypes.data, max_tri, ctypes.byref(nt),
+                                       c3.ctypes.data))
+        return dict(desc=desc[:nb], edge_matrix=em[:nb, :nb], eigenvalues=ev[:nb], edges=edges[:ne.value],
+                    edge_value=evalue[:ne.value], edge_weights=ew[:ne.value], tri_counts=tc[:nb],
+                    triangles=tri[:nt.value], counts=c3)
+
+    # ---- SemGraphSLAM::mainProcess ----
+    @staticmethod
+    def _result(res):
+        return dict(pose=np.array(res.pose[:]), initial_guess=np.array(res.initial_guess[:]), sigma=res.sigma,
+                    iterations=res.icp_iterations, n_raw=res.n_raw, n_in=res.n_in, n_cluster=res.n_cluster,
+                    n_ds=res.n_ds, n_src=res.n_src, n_boxes=res.n_boxes, map_voxels=res.map_voxels,
+                    correspondences=res.icp_correspondences, candidates=res.icp_candidates)
+
+    def mainProcess(self, frame, frame_label, timestamps=None, dataset=""):
+        xyz = _f64(frame); lab = _i32(frame_label)
+        ts = _f64(timestamps) if timestamps is not None and len(timestamps) else None
+        res = SgsScanResult(); res.size = ctypes.sizeof(SgsScanResult)
+        self._ck(lib().sgs_process_scan(self.h, xyz.ctypes.data, lab.ctypes.data, len(xyz),
+                                        ts.ctypes.data if ts is not None else None, int(dataset == "kitti"),
+                                        ctypes.byref(res)))
+        return self._result(res)
+
+    def process_scan_f32(self, xyzi, label, timestamps=None, dataset=""):
+        p = np.ascontiguousarray(xyzi, dtype=np.float32); lab = _i32(label)
+        ts = _f64(timestamps) if timestamps is not None and len(timestamps) else None
+        res = SgsScanResult(); res.size = ctypes.sizeof(SgsScanResult)
+        self._ck(lib().sgs_process_scan_f32(self.h, p.ctypes.data, lab.ctypes.data, len(p),
+                                            ts.ctypes.data if ts is not None else None, int(dataset == "kitti"),
+                                            ctypes.byref(res)))
+        return self._result(res)
+
+    def process_scan_dev(self, xyzi_ptr, label_ptr, n, ts_ptr=None, dataset="", res=None):
+        """Device-pointer variant (ints from torch.Tensor.data_ptr()); returns the raw SgsScanResult."""
+        if res is None:
+            res = SgsScanResult()
+        res.size = ctypes.sizeof(SgsScanResult)
+        self._ck(lib().sgs_process_scan_f32_dev(self.h, xyzi_ptr, label_ptr, int(n), ts_ptr, int(dataset == "kitti"),
+                                                ctypes.byref(res)))
+        return res
+
+    def cloud(self, which):
+        n = c_int()
+        self._ck(lib().sgs_get_cloud(self.h, int(which), None, None, 0, ctypes.byref(n)), allow_capacity=True)
+        xyz = np.empty((max(n.value, 1), 3)); lab = np.empty(max(n.value, 1), dtype=np.int32)
+        self._ck(lib().sgs_get_cloud(self.h, int(which), xyz.ctypes.data, lab.ctypes.data, n.value, ctypes.byref(n)))
+        return xyz[:n.value].copy(), lab[:n.value].copy()
+
+    def boxes(self):
+        n = c_int()
+        self._ck(lib().sgs_get_boxes(self.h, None, 0, ctypes.byref(n)), allow_capacity=True)
+        b = np.empty((max(n.value, 1), 8))
+        self._ck(lib().sgs_get_boxes(self.h, b.ctypes.data, n.value, ctypes.byref(n)))
+        return b[:n.value].copy()
+
+    def poses(self):
+        n = c_int()
+        self._ck(lib().sgs_get_poses(self.h, None, 0, ctypes.byref(n)), allow_capacity=True)
+        p = np.empty((max(n.value, 1), 7))
+        self._ck(lib().sgs_get_poses(self.h, p.ctypes.data, n.value, ctypes.byref(n)))
+        return p[:n.value].copy()

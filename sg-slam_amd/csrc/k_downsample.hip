@@ -1,0 +1,240 @@
+// VoxelDownsampleSemantic (F/Preprocessing.cpp:70-94) on device: keep the first point (lowest input
+// index) of every voxel and emit the survivors in the order tsl::robin_map would iterate them.
+//
+// Why the order matters: `source` is the 1.5 m downsample of the *output order* of the 0.5 m
+// downsample (P/SemGraphSLAM.cpp:129-130) and the map's per-voxel cap is first-come in that order
+// (F/VoxelHashMap.cpp:164-176), so the emission order is part of the result.
+//
+// The reference grid has B = pow2ceil(2n) buckets (reserve(n), max load 0.5) and iterates them in
+// ascending bucket index.  Robin-hood and plain linear probing occupy the SAME set of buckets, and
+// everything that ever happens to an element stays inside its maximal run of occupied buckets.  So:
+//   1 clear     B-slot scratch table
+//   2 insert    plain linear probing from the reference's home bucket (hash & (B-1)), atomicCAS on the
+//               packed integer key + atomicMin of the input index  -> occupied set + each voxel's
+//               first index (= its insertion time in the reference)
+//   3 scan      exclusive prefix sum of the occupancy flags: emission position of every bucket
+//   4 replay    one thread per run: sort the run's voxels by insertion time and replay the robin-hood
+//               insertions on the run's own buckets (displaced elements hop over equal-distance
+//               residents, so same-home elements are NOT simply in insertion order); write
+//               order[prefix[bucket]] = first index.  Runs are short at load <= 0.5 (a few buckets).
+//   5 gather    copy the points out in that order
+// All integer work, HBM/L2-bound; grids are sized by the host-known upper bound of n and read the
+// true n from device memory, so no host round trip is needed between stages.
+#include <climits>
+
+#include "sgs_device.h"
+
+namespace sgs {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kScanItems = 4;  // entries per thread in the occupancy scan
+constexpr int kScanTile = kBlock * kScanItems;
+
+struct DsJobs {
+    DsJob j[2];
+};
+
+__device__ inline uint32_t buckets_for(int n) {  // pow2ceil(ceil(n / 0.5))
+    uint32_t want = (uint32_t)n * 2u, b = 1;
+    while (b < want) b <<= 1;
+    return b;
+}
+
+__global__ __launch_bounds__(kBlock) void ds_clear_kernel(DsJobs jobs) {
+    const DsJob &J = jobs.j[blockIdx.y];
+    const int n = *J.n_in;
+    if (n <= 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *J.n_out = 0;
+        return;
+    }
+    const uint32_t B = buckets_for(n);
+    ulonglong2 *t = reinterpret_cast<ulonglong2 *>(J.table);
+    const ulonglong2 empty = make_ulonglong2(kEmptyKey, 0x00000000FFFFFFFFull);  // minidx = UINT_MAX
+    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < B; s += gridDim.x * kBlock) t[s] = empty;
+}
+
+__global__ __launch_bounds__(kBlock) void ds_insert_kernel(DsJobs jobs, DevState *st) {
+    const DsJob &J = jobs.j[blockIdx.y];
+    const int n = *J.n_in;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t mask = buckets_for(n) - 1u;
+    const K3 k = voxel_of(J.in.x[i], J.in.y[i], J.in.z[i], J.voxel);
+    if (!key_in_range(k)) atomicOr(&st->err_flags, ERR_KEY_RANGE);
+    const unsigned long long pk = pack_key(k);
+    uint32_t s = ref_hash(k) & mask;
+    while (true) {
+        // plain read first: a stale EMPTY only costs the CAS below; a non-EMPTY value is final
+        unsigned long long cur = J.table[s].key;
+        if (cur == kEmptyKey) {
+            cur = atomicCAS(&J.table[s].key, kEmptyKey, pk);
+            if (cur == kEmptyKey) break;
+        }
+        if (cur == pk) break;
+        s = (s + 1u) & mask;
+    }
+    // minidx only ever decreases, so a (possibly stale) value <= i proves the atomic is unnecessary
+    if (J.table[s].minidx > (uint32_t)i) atomicMin(&J.table[s].minidx, (uint32_t)i);
+}
+
+__global__ __launch_bounds__(kBlock) void ds_scan_a_kernel(DsJobs jobs) {
+    const DsJob &J = jobs.j[blockIdx.y];
+    const int n = *J.n_in;
+    if (n <= 0) return;
+    const uint32_t B = buckets_for(n);
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= B) return;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t s = base + threadIdx.x * kScanItems + k;
+        if (s < B) sum += J.table[s].key != kEmptyKey ? 1 : 0;
+    }
+    __shared__ int red[kBlock / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) J.blocksum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(kBlock) void ds_scan_b_kernel(DsJobs jobs) {
+    const DsJob &J = jobs.j[blockIdx.y];
+    const int n = *J.n_in;
+    if (n <= 0) return;
+    const uint32_t B = buckets_for(n);
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= B) return;
+    __shared__ int red[kBlock / 64];
+    __shared__ int wtot[kBlock / 64];
+    int part = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += kBlock) part += J.blocksum[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const int blockbase = red[0] + red[1] + red[2] + red[3];
+    int v[kScanItems], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t s = base + threadIdx.x * kScanItems + k;
+        v[k] = (s < B && J.table[s].key != kEmptyKey) ? 1 : 0;
+        mine += v[k];
+    }
+    int inc = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int wbase = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w)
+        if (w < wave) wbase += wtot[w];
+    int run = blockbase + wbase + inc - mine;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t s = base + threadIdx.x * kScanItems + k;
+        if (s < B) J.homebase[s] = run;
+        run += v[k];
+    }
+    // the block holding the last bucket publishes the number of distinct voxels
+    if (base + kScanTile >= B && threadIdx.x == kBlock - 1) *J.n_out = run;
+}
+
+// One thread per maximal run of occupied buckets: replay the reference's robin-hood insertions.
+// sim[] (2 ints per bucket) holds the run's elements sorted by insertion time, lay[] the layout.
+__global__ __launch_bounds__(kBlock) void ds_replay_kernel(DsJobs jobs) {
+    const DsJob &J = jobs.j[blockIdx.y];
+    const int n = *J.n_in;
+    if (n <= 0) return;
+    const uint32_t B = buckets_for(n), mask = B - 1u;
+    const uint32_t s0 = blockIdx.x * kBlock + threadIdx.x;
+    if (s0 >= B) return;
+    if (J.table[s0].key == kEmptyKey) return;
+    if (J.table[(s0 - 1u) & mask].key != kEmptyKey) return;  // not the first bucket of its run
+    int2 *sim = reinterpret_cast<int2 *>(J.sim);
+    int2 *lay = reinterpret_cast<int2 *>(J.lay);
+    // gather (relative home, first index), insertion-sorted by first index
+    uint32_t L = 0;
+    for (uint32_t u = 0; u < B; ++u) {
+        const DsEntry e = J.table[(s0 + u) & mask];
+        if (e.key == kEmptyKey) break;
+        const int home = (int)(((ref_hash(unpack_key(e.key)) & mask) - s0) & mask);
+        const int idx = (int)e.minidx;
+        int b = (int)u - 1;
+        while (b >= 0) {
+            const int2 q = sim[(s0 + (uint32_t)b) & mask];
+            if (q.y <= idx) break;
+            sim[(s0 + (uint32_t)b + 1u) & mask] = q;
+            --b;
+        }
+        sim[(s0 + (uint32_t)(b + 1)) & mask] = make_int2(home, idx);
+        lay[(s0 + u) & mask] = make_int2(-1, -1);
+        L = u + 1u;
+    }
+    // replay: a newcomer walks from its home while its distance <= the resident's, swaps when larger
+    // (distance compare == home compare at a fixed bucket), and the displaced element keeps walking
+    for (uint32_t t = 0; t < L; ++t) {
+        int2 cur = sim[(s0 + t) & mask];
+        uint32_t u = (uint32_t)cur.x;
+        while (true) {
+            const int2 r = lay[(s0 + u) & mask];
+            if (r.y < 0) {
+                lay[(s0 + u) & mask] = cur;
+                break;
+            }
+            if (cur.x < r.x) {
+                lay[(s0 + u) & mask] = cur;
+                cur = r;
+            }
+            if (++u >= L) break;  // cannot happen (the run has exactly L buckets); guards against a hang
+        }
+    }
+    for (uint32_t u = 0; u < L; ++u) {
+        const uint32_t s = (s0 + u) & mask;
+        J.order[J.homebase[s]] = lay[s].y;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ds_gather_kernel(DsJobs jobs) {
+    const DsJob &J = jobs.j[blockIdx.y];
+    const int n = *J.n_in;
+    if (n <= 0) return;
+    const int m = *J.n_out;
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= m) return;
+    const int i = J.order[k];
+    J.out.x[k] = J.in.x[i]; J.out.y[k] = J.in.y[i]; J.out.z[k] = J.in.z[i];
+    J.out.l[k] = J.in.l[i];
+    if (J.out_index) J.out_index[k] = i;
+}
+
+}  // namespace
+
+void launch_downsample(hipStream_t s, const DsJob *jobs, int njobs, int n_upper, DevState *st) {
+    if (n_upper <= 0 || njobs <= 0) return;
+    DsJobs js;
+    js.j[0] = jobs[0];
+    js.j[1] = jobs[njobs > 1 ? 1 : 0];
+    uint32_t Bmax = 1;
+    while (Bmax < (uint32_t)n_upper * 2u) Bmax <<= 1;
+    const int nb_pts = (n_upper + kBlock - 1) / kBlock;
+    const int nb_scan = (int)((Bmax + kScanTile - 1) / kScanTile);
+    const int nb_slots = (int)((Bmax + kBlock - 1) / kBlock);
+    const int nb_clear = nb_scan < 1024 ? nb_scan : 1024;
+    const dim3 blk(kBlock);
+    hipLaunchKernelGGL(ds_clear_kernel, dim3(nb_clear, njobs), blk, 0, s, js);
+    hipLaunchKernelGGL(ds_insert_kernel, dim3(nb_pts, njobs), blk, 0, s, js, st);
+    hipLaunchKernelGGL(ds_scan_a_kernel, dim3(nb_scan, njobs), blk, 0, s, js);
+    hipLaunchKernelGGL(ds_scan_b_kernel, dim3(nb_scan, njobs), blk, 0, s, js);
+    hipLaunchKernelGGL(ds_replay_kernel, dim3(nb_slots, njobs), blk, 0, s, js);
+    hipLaunchKernelGGL(ds_gather_kernel, dim3(nb_pts, njobs), blk, 0, s, js);
+}
+
+}  // namespace sgs

@@ -1,0 +1,239 @@
+// GPU-resident voxel hash map (F/VoxelHashMap.{hpp,cpp}): open addressing with linear probing over
+// 16-byte slot headers {packed key, count, pending-list head}; slot s owns the storage block
+// pts[s*cap .. s*cap+cap) of voxel-local fp32 offsets + label, so a find is one 16-B load and a
+// voxel's points are one contiguous coalesced read.
+//
+// AddPoints semantics to preserve (F/VoxelHashMap.cpp:164-176): points are inserted sequentially in
+// input order and a voxel keeps at most `cap` points first-come.  Parallel version:
+//   add kernel     every point finds-or-claims its slot (atomicCAS on the key) and pushes itself on
+//                  the slot's pending list (atomicExch on head)
+//   append kernel  the point that ended up as list head owns the slot: it walks the list, picks the
+//                  (cap - cnt) smallest input indices in ascending order and appends exactly those,
+//                  which is what the sequential loop would have stored.
+// Prune (F/VoxelHashMap.cpp:178-186): a sweep over the slot headers that tombstones voxels whose
+// oldest point is farther than max_distance from the origin (pure predicate; the reference's
+// erase-while-iterating skip quirk is layout dependent and not reproduced).
+#include <climits>
+
+#include "sgs_device.h"
+
+namespace sgs {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void map_init_kernel(MapView m) {
+    const uint32_t cap = m.mask + 1u;
+    ulonglong2 *t = reinterpret_cast<ulonglong2 *>(m.slots);
+    // key = EMPTY, cnt = 0, head = -1
+    const ulonglong2 empty = make_ulonglong2(kEmptyKey, 0xFFFFFFFF00000000ull);
+    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < cap; s += gridDim.x * kBlock) t[s] = empty;
+}
+
+__global__ void map_reset_counters_kernel(DevState *st) {
+    st->map_live = 0; st->map_tomb = 0; st->map_points = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void map_add_kernel(MapView m, CloudView in, const int32_t *__restrict__ n_ptr,
+                                                         const Rigid *__restrict__ T_dev, int32_t *__restrict__ slot_of,
+                                                         int32_t *__restrict__ next, CloudView world, DevState *st) {
+    const int n = *n_ptr;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    D3 p{in.x[i], in.y[i], in.z[i]};
+    if (T_dev) p = apply(*T_dev, p);
+    world.x[i] = p.x; world.y[i] = p.y; world.z[i] = p.z;
+    const K3 k = voxel_of(p.x, p.y, p.z, m.voxel);
+    if (!key_in_range(k)) {
+        atomicOr(&st->err_flags, ERR_KEY_RANGE);
+        slot_of[i] = -1;
+        return;
+    }
+    const unsigned long long pk = pack_key(k);
+    uint32_t s = map_hash(pk) & m.mask;
+    int found = -1;
+    for (uint32_t step = 0; step <= m.mask; ++step) {
+        unsigned long long cur = m.slots[s].key;
+        if (cur == kEmptyKey) {
+            cur = atomicCAS(&m.slots[s].key, kEmptyKey, pk);
+            if (cur == kEmptyKey) {
+                found = (int)s;
+                break;
+            }
+        }
+        if (cur == pk) { found = (int)s; break; }
+        s = (s + 1u) & m.mask;
+    }
+    if (found < 0) {
+        atomicOr(&st->err_flags, ERR_MAP_FULL);
+        slot_of[i] = -1;
+        return;
+    }
+    slot_of[i] = found;
+    next[i] = atomicExch(&m.slots[found].head, i);
+}
+
+__global__ __launch_bounds__(kBlock) void map_append_kernel(MapView m, CloudView in, const int32_t *__restrict__ n_ptr,
+                                                            const int32_t *__restrict__ slot_of,
+                                                            const int32_t *__restrict__ next, CloudView world,
+                                                            DevState *st) {
+    const int n = *n_ptr;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int s = slot_of[i];
+    if (s < 0) return;
+    if (m.slots[s].head != i) return;  // only the list head processes the voxel
+    const uint32_t cnt0 = m.slots[s].cnt;
+    const int room = m.cap - (int)cnt0;
+    const K3 k = unpack_key(m.slots[s].key);
+    const double ox = (double)k.x * m.voxel, oy = (double)k.y * m.voxel, oz = (double)k.z * m.voxel;
+    int last = -1, written = 0;
+    for (int r = 0; r < room; ++r) {
+        int best = INT_MAX;
+        for (int j = i; j >= 0; j = next[j])
+            if (j > last && j < best) best = j;
+        if (best == INT_MAX) break;
+        const double wx = world.x[best], wy = world.y[best], wz = world.z[best];
+        const uint32_t slotpos = cnt0 + (uint32_t)written;
+        m.pts[(size_t)s * m.cap + slotpos] =
+            make_float4((float)(wx - ox), (float)(wy - oy), (float)(wz - oz), __int_as_float(in.l[best]));
+        if (slotpos == 0) {
+            m.first[3 * (size_t)s] = wx; m.first[3 * (size_t)s + 1] = wy; m.first[3 * (size_t)s + 2] = wz;
+        }
+        last = best;
+        ++written;
+    }
+    m.slots[s].cnt = cnt0 + (uint32_t)written;
+    m.slots[s].head = -1;
+    (void)st;
+}
+
+// Sweep over all slot headers: optional prune + per-block census (live voxels, tombstones, points);
+// map_census_kernel folds the per-block numbers into DevState so no contended atomics are needed.
+__global__ __launch_bounds__(kBlock) void map_prune_kernel(MapView m, const Rigid *__restrict__ T_dev, D3 origin_host,
+                                                           double max_d2, int do_prune, int4 *__restrict__ blockstat) {
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    int live = 0, tomb = 0, pts = 0;
+    if (s <= m.mask) {
+        const MapSlot e = m.slots[s];
+        if (e.key == kTombKey) {
+            tomb = 1;
+        } else if (e.key != kEmptyKey) {
+            bool kill = false;
+            if (do_prune) {
+                const D3 o = T_dev ? T_dev->t : origin_host;
+                const D3 f{m.first[3 * (size_t)s], m.first[3 * (size_t)s + 1], m.first[3 * (size_t)s + 2]};
+                kill = sq3(sub(f, o)) > max_d2;
+            }
+            if (kill) {
+                m.slots[s].key = kTombKey;
+                m.slots[s].cnt = 0;
+                tomb = 1;
+            } else {
+                live = 1;
+                pts = (int)e.cnt;
+            }
+        }
+    }
+    __shared__ int red[3][kBlock / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        live += __shfl_down(live, o);
+        tomb += __shfl_down(tomb, o);
+        pts += __shfl_down(pts, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = live; red[1][threadIdx.x >> 6] = tomb; red[2][threadIdx.x >> 6] = pts;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        blockstat[blockIdx.x] = make_int4(red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3],
+                                          red[2][0] + red[2][1] + red[2][2] + red[2][3], 0);
+}
+
+__global__ __launch_bounds__(kBlock) void map_census_kernel(const int4 *__restrict__ blockstat, int nblocks, DevState *st) {
+    int live = 0, tomb = 0, pts = 0;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const int4 v = blockstat[b];
+        live += v.x; tomb += v.y; pts += v.z;
+    }
+    __shared__ int red[3][kBlock / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        live += __shfl_down(live, o);
+        tomb += __shfl_down(tomb, o);
+        pts += __shfl_down(pts, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = live; red[1][threadIdx.x >> 6] = tomb; red[2][threadIdx.x >> 6] = pts;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->map_live = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        st->map_tomb = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        st->map_points = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void map_rehash_kernel(MapView from, MapView to, DevState *st) {
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    if (s > from.mask) return;
+    const MapSlot e = from.slots[s];
+    if (e.key == kEmptyKey || e.key == kTombKey) return;
+    uint32_t d = map_hash(e.key) & to.mask;
+    for (uint32_t step = 0; step <= to.mask; ++step) {
+        if (atomicCAS(&to.slots[d].key, kEmptyKey, e.key) == kEmptyKey) break;
+        d = (d + 1u) & to.mask;
+    }
+    to.slots[d].cnt = e.cnt;
+    for (uint32_t j = 0; j < e.cnt; ++j) to.pts[(size_t)d * to.cap + j] = from.pts[(size_t)s * from.cap + j];
+    to.first[3 * (size_t)d] = from.first[3 * (size_t)s];
+    to.first[3 * (size_t)d + 1] = from.first[3 * (size_t)s + 1];
+    to.first[3 * (size_t)d + 2] = from.first[3 * (size_t)s + 2];
+    (void)st;
+}
+
+__global__ void map_after_rehash_kernel(DevState *st) { st->map_tomb = 0; }
+
+}  // namespace
+
+void launch_map_init(hipStream_t s, MapView m) {
+    const uint32_t cap = m.mask + 1u;
+    int nb = (int)((cap + kBlock - 1) / kBlock);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(map_init_kernel, dim3(nb), dim3(kBlock), 0, s, m);
+}
+
+void launch_map_clear(hipStream_t s, MapView m, DevState *st) {
+    launch_map_init(s, m);
+    hipLaunchKernelGGL(map_reset_counters_kernel, dim3(1), dim3(1), 0, s, st);
+}
+
+void launch_map_add(hipStream_t s, MapView m, CloudView in, const int32_t *n_ptr, int n_upper, const Rigid *T_dev,
+                    int32_t *slot_of, int32_t *next, CloudView world, DevState *st) {
+    if (n_upper <= 0) return;
+    const int nb = (n_upper + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(map_add_kernel, dim3(nb), dim3(kBlock), 0, s, m, in, n_ptr, T_dev, slot_of, next, world, st);
+    hipLaunchKernelGGL(map_append_kernel, dim3(nb), dim3(kBlock), 0, s, m, in, n_ptr, slot_of, next, world, st);
+}
+
+void launch_map_sweep(hipStream_t s, MapView m, const Rigid *T_dev, const double *origin3_host, double max_dist,
+                      int do_prune, int4 *blockstat, DevState *st) {
+    const uint32_t cap = m.mask + 1u;
+    D3 o{0, 0, 0};
+    if (origin3_host) o = D3{origin3_host[0], origin3_host[1], origin3_host[2]};
+    const int nb = (int)((cap + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(map_prune_kernel, dim3(nb), dim3(kBlock), 0, s, m, T_dev, o, max_dist * max_dist, do_prune,
+                       blockstat);
+    hipLaunchKernelGGL(map_census_kernel, dim3(1), dim3(kBlock), 0, s, blockstat, nb, st);
+}
+
+void launch_map_rehash(hipStream_t s, MapView from, MapView to, DevState *st) {
+    launch_map_init(s, to);
+    const uint32_t cap = from.mask + 1u;
+    hipLaunchKernelGGL(map_rehash_kernel, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, from, to, st);
+    hipLaunchKernelGGL(map_after_rehash_kernel, dim3(1), dim3(1), 0, s, st);
+}
+
+}  // namespace sgs

@@ -1,0 +1,146 @@
+// Per-point pre-steps of the scan: float->double widening (ros/ros1/InsUtils.hpp:531), DeSkewScan
+// (F/Deskew.cpp:37-48), CorrectKITTIScan (F/Preprocessing.cpp:127-137) and the PreprocessSemantic
+// crop (F/Preprocessing.cpp:107-125) as one fused pass + an order-preserving compaction.
+// HBM-bound streaming kernels: one coalesced read of the raw scan, one write of the kept points.
+#include "sgs_device.h"
+
+namespace sgs {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ inline D3 kitti_correct(D3 p, double s, double c) {
+    // rotation by the fixed angle about normalize(p x z); zero cross product is left unnormalised
+    D3 ax = crs(p, D3{0., 0., 1.});
+    const double n2 = sq3(ax);
+    if (n2 > 0) {
+        const double n = sqrt(n2);
+        ax = D3{ax.x / n, ax.y / n, ax.z / n};
+    }
+    const D3 c1 = scale(1.0 - c, ax);
+    double m[3][3];
+    double t;
+    t = c1.x * ax.y; m[0][1] = t - s * ax.z; m[1][0] = t + s * ax.z;
+    t = c1.x * ax.z; m[0][2] = t + s * ax.y; m[2][0] = t - s * ax.y;
+    t = c1.y * ax.z; m[1][2] = t - s * ax.x; m[2][1] = t + s * ax.x;
+    m[0][0] = c1.x * ax.x + c;
+    m[1][1] = c1.y * ax.y + c;
+    m[2][2] = c1.z * ax.z + c;
+    return D3{m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z, m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z,
+              m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z};
+}
+
+// exclusive rank of a boolean within the block + block total (256 threads = 4 waves)
+__device__ inline int block_rank(bool flag, int *total) {
+    __shared__ int wsum[kBlock / 64];
+    const unsigned long long b = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(b);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        if (w < wave) base += wsum[w];
+        tot += wsum[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + r;
+}
+
+__global__ __launch_bounds__(kBlock) void pre_transform_kernel(const float *__restrict__ in_f32,
+                                                               const double *__restrict__ in_f64,
+                                                               const int32_t *__restrict__ label,
+                                                               const double *__restrict__ ts, int n, PreParams p,
+                                                               CloudView tmp, int32_t *__restrict__ flags,
+                                                               int32_t *__restrict__ blockcnt) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+        D3 q;
+        if (in_f32) {
+            const float4 v = reinterpret_cast<const float4 *>(in_f32)[i];
+            q = D3{(double)v.x, (double)v.y, (double)v.z};
+        } else {
+            q = D3{in_f64[3 * (size_t)i], in_f64[3 * (size_t)i + 1], in_f64[3 * (size_t)i + 2]};
+        }
+        const D3 raw = q;
+        if (p.mode_deskew) {
+            double a[6];
+            const double f = ts[i] - 0.5;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) a[k] = f * p.delta[k];
+            q = apply(rigid_exp(a), raw);
+        }
+        if (p.mode_kitti) q = kitti_correct(raw, p.sin_a, p.cos_a);  // overwrites deskew (P/SemGraphSLAM.cpp:30-33)
+        tmp.x[i] = q.x; tmp.y[i] = q.y; tmp.z[i] = q.z;
+        if (p.crop) {
+            const double nrm = sqrt(sq3(q));
+            keep = nrm < p.max_range && nrm > p.min_range && label[i] < 20;
+        } else {
+            keep = true;
+        }
+        flags[i] = keep ? 1 : 0;
+    }
+    int total;
+    (void)block_rank(keep, &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void pre_compact_kernel(const int32_t *__restrict__ label, int n, CloudView tmp,
+                                                             const int32_t *__restrict__ flags,
+                                                             const int32_t *__restrict__ blockcnt, CloudView out,
+                                                             int32_t *__restrict__ n_out) {
+    __shared__ int red[kBlock / 64];
+    // base = sum of the counts of all previous blocks (<= 4096 blocks: cheaper than a scan launch)
+    int part = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += kBlock) part += blockcnt[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const int base = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool keep = (i < n) && flags[i] != 0;
+    int total;
+    const int r = block_rank(keep, &total);
+    if (keep) {
+        const int o = base + r;
+        out.x[o] = tmp.x[i]; out.y[o] = tmp.y[i]; out.z[o] = tmp.z[i];
+        out.l[o] = label ? label[i] : 0;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = base + total;
+}
+
+__global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const double *__restrict__ xyz, int n, double voxel,
+                                                            int32_t *__restrict__ keys) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const K3 k = voxel_of(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], voxel);
+    keys[3 * (size_t)i] = k.x; keys[3 * (size_t)i + 1] = k.y; keys[3 * (size_t)i + 2] = k.z;
+}
+
+}  // namespace
+
+void launch_preprocess(hipStream_t s, const float *in_f32, const double *in_f64, const int32_t *label,
+                       const double *timestamps, int n, const PreParams &p, CloudView tmp, int32_t *flags,
+                       int32_t *blockcnt, CloudView out, int32_t *n_out) {
+    if (n <= 0) {
+        hipMemsetAsync(n_out, 0, sizeof(int32_t), s);
+        return;
+    }
+    const int nb = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(pre_transform_kernel, dim3(nb), dim3(kBlock), 0, s, in_f32, in_f64, label, timestamps, n, p,
+                       tmp, flags, blockcnt);
+    hipLaunchKernelGGL(pre_compact_kernel, dim3(nb), dim3(kBlock), 0, s, label, n, tmp, flags, blockcnt, out, n_out);
+}
+
+void launch_voxel_keys(hipStream_t s, const double *xyz, int n, double voxel, int32_t *keys) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, xyz, n, voxel, keys);
+}
+
+}  // namespace sgs

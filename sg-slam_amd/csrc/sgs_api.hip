@@ -1,0 +1,949 @@
+// Host side of libsgs_hip.so: context (device buffers, one HIP stream), the C ABI of include/sgs.h
+// and the per-scan orchestration that restates SemGraphSLAM::mainProcess
+// (P/SemGraphSLAM.cpp:16-121) around the device kernels.  There is no CPU fallback anywhere in this
+// file: every compute entry point launches HIP kernels or fails with SGS_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sgs.h"
+#include "sgs_device.h"
+#include "sgs_graph.h"
+
+using namespace sgs;
+
+namespace {
+
+struct CloudBuf {
+    CloudView v{nullptr, nullptr, nullptr, nullptr};
+};
+
+struct MapBuf {
+    MapView v{nullptr, nullptr, nullptr, 0, 0, 0.0};
+    int log2cap = 0;
+};
+
+}  // namespace
+
+struct sgs_ctx {
+    sgs_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;
+    int N = 0;  // max points per scan
+
+    // inputs
+    float *in_f32 = nullptr;
+    double *in_f64 = nullptr;
+    int32_t *in_label = nullptr;
+    double *in_ts = nullptr;
+    // clouds
+    CloudView tmp, cropped, cluster, ds, src, world, aux;
+    int32_t *flags = nullptr, *blockcnt = nullptr;
+    // downsample scratch (two jobs)
+    DsEntry *ds_table[2] = {nullptr, nullptr};
+    int32_t *ds_homebase[2] = {nullptr, nullptr}, *ds_blocksum[2] = {nullptr, nullptr};
+    int32_t *ds_sim[2] = {nullptr, nullptr}, *ds_lay[2] = {nullptr, nullptr}, *ds_order[2] = {nullptr, nullptr};
+    int32_t *ds_index = nullptr;  // out_index for the granular call
+    int32_t *aux_n = nullptr;     // device ints for granular calls [8]
+    // map
+    MapBuf map;
+    int32_t *map_slot_of = nullptr, *map_next = nullptr;
+    int4 *map_blockstat = nullptr;
+    // icp
+    double *partials = nullptr, *out28 = nullptr;
+    double *corr_tgt = nullptr;
+    int32_t *corr_found = nullptr;
+    // state
+    DevState *st = nullptr;
+    DevState *st_host = nullptr;  // pinned
+    // cluster / graph
+    GraphScratch gs;
+
+    // host-side SLAM state (P/SemGraphSLAM.hpp:105-111, F/Threshold.hpp:45-52)
+    std::vector<Rigid> poses;
+    double model_error_sse2 = 0.0;
+    int num_samples = 0;
+    Rigid model_deviation = rigid_identity();
+    int map_live_host = 0, map_tomb_host = 0, map_points_host = 0;
+    int prev_iters = 6;
+    int last_n[5] = {0, 0, 0, 0, 0};
+    std::vector<double> last_boxes;
+
+    // profiling
+    bool profiling = false;
+    sgs_stats stats;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> icp_events;
+    size_t icp_events_used = 0;
+    hipEvent_t stage_ev[8];
+    bool stage_ev_ok = false;
+};
+
+namespace {
+
+int fail(sgs_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define SGS_HIP(c, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail((c), SGS_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+int dev_alloc(sgs_ctx *c, T **p, size_t count) {
+    void *q = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess) return fail(c, SGS_ENOMEM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return SGS_OK;
+}
+
+int alloc_cloud(sgs_ctx *c, CloudView *v, size_t n) {
+    int r;
+    if ((r = dev_alloc(c, &v->x, n))) return r;
+    if ((r = dev_alloc(c, &v->y, n))) return r;
+    if ((r = dev_alloc(c, &v->z, n))) return r;
+    if ((r = dev_alloc(c, &v->l, n))) return r;
+    return SGS_OK;
+}
+
+int alloc_map(sgs_ctx *c, MapBuf *m, int log2cap) {
+    const size_t cap = (size_t)1 << log2cap;
+    void *a = nullptr, *b = nullptr, *d = nullptr;
+    if (hipMalloc(&a, cap * sizeof(MapSlot)) != hipSuccess || hipMalloc(&b, cap * (size_t)c->cfg.max_points_per_voxel * sizeof(float4)) != hipSuccess ||
+        hipMalloc(&d, cap * 3 * sizeof(double)) != hipSuccess) {
+        if (a) hipFree(a);
+        if (b) hipFree(b);
+        if (d) hipFree(d);
+        return fail(c, SGS_ENOMEM, "voxel map allocation failed (2^%d slots)", log2cap);
+    }
+    m->v.slots = (MapSlot *)a;
+    m->v.pts = (float4 *)b;
+    m->v.first = (double *)d;
+    m->v.mask = (uint32_t)(cap - 1);
+    m->v.cap = c->cfg.max_points_per_voxel;
+    m->v.voxel = c->cfg.voxel_size;
+    m->log2cap = log2cap;
+    return SGS_OK;
+}
+void free_map(MapBuf *m) {
+    if (m->v.slots) hipFree(m->v.slots);
+    if (m->v.pts) hipFree(m->v.pts);
+    if (m->v.first) hipFree(m->v.first);
+    m->v.slots = nullptr; m->v.pts = nullptr; m->v.first = nullptr;
+}
+
+int sync_state(sgs_ctx *c) {
+    SGS_HIP(c, hipMemcpyAsync(c->st_host, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    SGS_HIP(c, hipStreamSynchronize(c->stream));
+    c->map_live_host = c->st_host->map_live;
+    c->map_tomb_host = c->st_host->map_tomb;
+    c->map_points_host = c->st_host->map_points;
+    return SGS_OK;
+}
+
+int check_err_flags(sgs_ctx *c) {
+    const int f = c->st_host->err_flags;
+    if (!f) return SGS_OK;
+    hipMemsetAsync(&c->st->err_flags, 0, sizeof(int32_t), c->stream);
+    if (f & ERR_MAP_FULL) return fail(c, SGS_ECAPACITY, "voxel map table full");
+    if (f & ERR_KEY_RANGE) return fail(c, SGS_ECAPACITY, "voxel key outside the packable range (+-2^20 voxels)");
+    return fail(c, SGS_ECAPACITY, "device error flags 0x%x", f);
+}
+
+// grow / rebuild the map when live + tombstones exceed half the table
+int maybe_rehash(sgs_ctx *c, int incoming) {
+    const long cap = 1L << c->map.log2cap;
+    const long used = (long)c->map_live_host + c->map_tomb_host + incoming;
+    if (used * 2 <= cap) return SGS_OK;
+    int log2 = c->map.log2cap;
+    while (((long)c->map_live_host + incoming) * 4 > (1L << log2)) ++log2;
+    MapBuf nm;
+    int r = alloc_map(c, &nm, log2);
+    if (r) return r;
+    launch_map_rehash(c->stream, c->map.v, nm.v, c->st);
+    SGS_HIP(c, hipStreamSynchronize(c->stream));
+    free_map(&c->map);
+    c->map = nm;
+    // blockstat must cover the new capacity
+    c->stats.map_rehashes++;
+    c->map_tomb_host = 0;
+    return SGS_OK;
+}
+
+int upload_xyz(sgs_ctx *c, const double *xyz, int n, CloudView dst, const int32_t *label) {
+    // host AoS (n*3) -> device SoA through the f64 staging buffer + a trivial preprocess pass
+    SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (label) SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    PreParams p{};
+    p.crop = 0;
+    launch_preprocess(c->stream, nullptr, c->in_f64, label ? c->in_label : nullptr, nullptr, n, p, c->tmp, c->flags,
+                      c->blockcnt, dst, &c->aux_n[0]);
+    return SGS_OK;
+}
+
+int upload_xyzl(sgs_ctx *c, const double *xyzl, int n, CloudView dst) {
+    std::vector<double> xyz((size_t)n * 3);
+    std::vector<int32_t> lab((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        xyz[3 * (size_t)i] = xyzl[4 * (size_t)i];
+        xyz[3 * (size_t)i + 1] = xyzl[4 * (size_t)i + 1];
+        xyz[3 * (size_t)i + 2] = xyzl[4 * (size_t)i + 2];
+        lab[(size_t)i] = (int32_t)xyzl[4 * (size_t)i + 3];
+    }
+    int r = upload_xyz(c, xyz.data(), n, dst, lab.data());
+    if (r) return r;
+    SGS_HIP(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    return SGS_OK;
+}
+
+int download_cloud(sgs_ctx *c, CloudView v, int n, double *xyz, int32_t *label) {
+    if (n <= 0) return SGS_OK;
+    if (xyz) {
+        std::vector<double> t((size_t)n * 3);
+        SGS_HIP(c, hipMemcpyAsync(t.data(), v.x, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        SGS_HIP(c, hipMemcpyAsync(t.data() + n, v.y, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        SGS_HIP(c, hipMemcpyAsync(t.data() + 2 * (size_t)n, v.z, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        SGS_HIP(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < n; ++i) {
+            xyz[3 * (size_t)i] = t[(size_t)i];
+            xyz[3 * (size_t)i + 1] = t[(size_t)n + i];
+            xyz[3 * (size_t)i + 2] = t[2 * (size_t)n + i];
+        }
+    }
+    if (label) {
+        SGS_HIP(c, hipMemcpyAsync(label, v.l, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        SGS_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return SGS_OK;
+}
+
+int read_dev_int(sgs_ctx *c, const int32_t *p, int *out) {
+    int32_t v = 0;
+    SGS_HIP(c, hipMemcpyAsync(&v, p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    SGS_HIP(c, hipStreamSynchronize(c->stream));
+    *out = v;
+    return SGS_OK;
+}
+
+DsJob make_job(sgs_ctx *c, int which, CloudView in, const int32_t *n_in, double voxel, CloudView out, int32_t *n_out,
+               int32_t *out_index) {
+    DsJob j;
+    j.in = in; j.n_in = n_in; j.voxel = voxel;
+    j.table = c->ds_table[which]; j.homebase = c->ds_homebase[which]; j.blocksum = c->ds_blocksum[which];
+    j.sim = c->ds_sim[which]; j.lay = c->ds_lay[which]; j.order = c->ds_order[which];
+    j.out = out; j.out_index = out_index; j.n_out = n_out;
+    return j;
+}
+
+bool bad_ctx(sgs_ctx *c) { return c == nullptr; }
+
+// P/SemGraphSLAM.cpp:147-159 + F/Threshold.cpp:29-50
+double adaptive_threshold(sgs_ctx *c) {
+    bool moved = false;
+    if (!c->poses.empty()) {
+        const Rigid d = compose(invert(c->poses.front()), c->poses.back());
+        moved = sqrt(sq3(d.t)) > 5.0 * c->cfg.min_motion_th;
+    }
+    if (!moved) return c->cfg.initial_threshold;
+    const double theta = rigid_rotation_angle(c->model_deviation);
+    const double delta_rot = 2.0 * c->cfg.max_range * sin(theta / 2.0);
+    const double delta_trans = sqrt(sq3(c->model_deviation.t));
+    const double model_error = delta_trans + delta_rot;
+    if (model_error > c->cfg.min_motion_th) {
+        c->model_error_sse2 += model_error * model_error;
+        c->num_samples++;
+    }
+    if (c->num_samples < 1) return c->cfg.initial_threshold;
+    return sqrt(c->model_error_sse2 / c->num_samples);
+}
+
+int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const Rigid &guess, double max_corr, double kernel_th,
+            int *iters_out) {
+    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, 500, 0);
+    *iters_out = 0;
+    if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
+    int launched = 0;
+    int chunk = std::min(32, std::max(4, c->prev_iters + 2));
+    while (true) {
+        for (int k = 0; k < chunk; ++k) {
+            if (c->profiling) {
+                if (c->icp_events_used == c->icp_events.size()) {
+                    hipEvent_t a, b;
+                    SGS_HIP(c, hipEventCreate(&a));
+                    SGS_HIP(c, hipEventCreate(&b));
+                    c->icp_events.emplace_back(a, b);
+                }
+                auto &ev = c->icp_events[c->icp_events_used++];
+                SGS_HIP(c, hipEventRecord(ev.first, c->stream));
+                launch_icp_iteration(c->stream, c->map.v, src, n_ptr, c->st, c->partials, false);
+                SGS_HIP(c, hipEventRecord(ev.second, c->stream));
+                launch_icp_iteration_solve_only(c->stream, c->st, c->partials);
+            } else {
+                launch_icp_iteration(c->stream, c->map.v, src, n_ptr, c->st, c->partials, true);
+            }
+        }
+        launched += chunk;
+        SGS_HIP(c, hipMemcpyAsync(c->st_host, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+        SGS_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->st_host->icp_done || launched >= 500) break;
+        chunk = 8;
+    }
+    *iters_out = c->st_host->icp_iter;
+    c->prev_iters = c->st_host->icp_iter;
+    return SGS_OK;
+}
+
+void drain_icp_events(sgs_ctx *c, int iterations_run) {
+    // only the first `iterations_run` launches did work; later ones exited on the done flag
+    for (size_t k = 0; k < c->icp_events_used; ++k) {
+        float ms = 0.f;
+        if ((int)k < iterations_run && hipEventElapsedTime(&ms, c->icp_events[k].first, c->icp_events[k].second) == hipSuccess) {
+            c->stats.icp_kernel_ms_total += ms;
+            c->stats.icp_kernel_launches++;
+        }
+    }
+    c->icp_events_used = 0;
+}
+
+int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const int32_t *d_label, int n,
+                     const double *d_ts, int is_kitti, sgs_scan_result *res) {
+    if (n < 0 || n > c->N) return fail(c, SGS_ECAPACITY, "scan of %d points exceeds max_points=%d", n, c->N);
+    hipStream_t s = c->stream;
+    const sgs_config &cfg = c->cfg;
+    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[0], s);
+    // ---- deskew / KITTI correction / crop (P/SemGraphSLAM.cpp:18-36)
+    PreParams p{};
+    p.crop = 1;
+    p.max_range = cfg.max_range;
+    p.min_range = cfg.min_range;
+    p.mode_kitti = is_kitti ? 1 : 0;
+    const double a = (0.205 * M_PI) / 180.0;
+    p.sin_a = sin(a);
+    p.cos_a = cos(a);
+    if (cfg.deskew && d_ts && c->poses.size() > 2) {
+        const size_t N = c->poses.size();
+        p.mode_deskew = 1;
+        rigid_log(compose(invert(c->poses[N - 2]), c->poses[N - 1]), p.delta);
+    }
+    launch_preprocess(s, d_f32, d_f64, d_label, d_ts, n, p, c->tmp, c->flags, c->blockcnt, c->cropped, &c->st->n_in);
+    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[1], s);
+    // ---- VoxelizeSemantic (P/SemGraphSLAM.cpp:124-132): 0.2 m and 0.5*voxel grids together, then 1.5*voxel
+    DsJob jobs[2];
+    jobs[0] = make_job(c, 0, c->cropped, &c->st->n_in, cfg.voxel_size_cluster, c->cluster, &c->st->n_c, nullptr);
+    jobs[1] = make_job(c, 1, c->cropped, &c->st->n_in, cfg.voxel_size * 0.5, c->ds, &c->st->n_d, nullptr);
+    launch_downsample(s, jobs, 2, n, c->st);
+    DsJob j3 = make_job(c, 0, c->ds, &c->st->n_d, cfg.voxel_size * 1.5, c->src, &c->st->n_s, nullptr);
+    launch_downsample(s, &j3, 1, n, c->st);
+    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[2], s);
+    // ---- motion prediction and threshold (P/SemGraphSLAM.cpp:57-63)
+    const double sigma = adaptive_threshold(c);
+    Rigid prediction = rigid_identity();
+    const size_t NP = c->poses.size();
+    if (NP >= 2) prediction = compose(invert(c->poses[NP - 2]), c->poses[NP - 1]);
+    const Rigid last_pose = NP ? c->poses.back() : rigid_identity();
+    const Rigid guess = compose(last_pose, prediction);
+    // ---- registration (P/SemGraphSLAM.cpp:72-76)
+    int iters = 0;
+    int r = run_icp(c, c->src, &c->st->n_s, guess, 3.0 * sigma, sigma / 3.0, &iters);
+    if (r) return r;
+    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[3], s);
+    // ---- local map update with the new pose, still on the device (P/SemGraphSLAM.cpp:113)
+    r = maybe_rehash(c, n);
+    if (r) return r;
+    launch_map_add(s, c->map.v, c->ds, &c->st->n_d, n, &c->st->T_total, c->map_slot_of, c->map_next, c->world, c->st);
+    launch_map_sweep(s, c->map.v, &c->st->T_total, nullptr, cfg.max_range, 1, c->map_blockstat, c->st);
+    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[4], s);
+    // ---- instance clustering + graph (P/SemGraphSLAM.cpp:41-51) on the 0.2 m cloud
+    int n_boxes = 0;
+    if (cfg.enable_graph) {
+        r = graph_process_scan(c->stream, c->gs, c->cluster, &c->st->n_c, n, cfg, &c->last_boxes, &n_boxes, &c->err);
+        if (r) return r;
+    }
+    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[5], s);
+    r = sync_state(c);
+    if (r) return r;
+    r = check_err_flags(c);
+    if (r) return r;
+    const DevState &h = *c->st_host;
+    const Rigid new_pose = h.T_total;
+    // ---- model deviation / pose list (P/SemGraphSLAM.cpp:79,110,119)
+    c->model_deviation = compose(invert(guess), new_pose);
+    c->poses.push_back(new_pose);
+    c->last_n[0] = n; c->last_n[1] = h.n_in; c->last_n[2] = h.n_c; c->last_n[3] = h.n_d; c->last_n[4] = h.n_s;
+    c->stats.scans++;
+    c->stats.icp_queries_total += (int64_t)h.n_s * iters;
+    c->stats.icp_candidates_total += h.icp_cand;
+    c->stats.icp_probes_total += h.icp_probe;
+    if (c->profiling) {
+        drain_icp_events(c, iters);
+        if (c->stage_ev_ok)
+            for (int k = 0; k < 5; ++k) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, c->stage_ev[k], c->stage_ev[k + 1]) == hipSuccess) c->stats.stage_ms[k] += ms;
+            }
+    }
+    if (res) {
+        const uint32_t sz = res->size ? std::min<uint32_t>(res->size, sizeof(sgs_scan_result)) : sizeof(sgs_scan_result);
+        sgs_scan_result o;
+        memset(&o, 0, sizeof(o));
+        o.size = sz;
+        o.icp_iterations = iters;
+        rigid_to_pose7(new_pose, o.pose);
+        rigid_to_pose7(guess, o.initial_guess);
+        o.sigma = sigma;
+        o.n_raw = n; o.n_in = h.n_in; o.n_cluster = h.n_c; o.n_ds = h.n_d; o.n_src = h.n_s;
+        o.n_boxes = n_boxes;
+        o.map_voxels = h.map_live;
+        o.icp_correspondences = h.icp_corr;
+        o.icp_candidates = h.icp_cand;
+        memcpy(res, &o, sz);
+    }
+    return SGS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void sgs_default_config(sgs_config *cfg) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->size = sizeof(sgs_config);
+    cfg->voxel_size = 1.0; cfg->voxel_size_cluster = 0.2; cfg->max_range = 100.0; cfg->min_range = 5.0;
+    cfg->max_points_per_voxel = 20;
+    cfg->min_motion_th = 0.1; cfg->initial_threshold = 2.0;
+    cfg->model_deviation_trans = 0.1; cfg->model_deviation_rot = 0.01; cfg->inlier_rate_th = 0.4;
+    cfg->deskew = 0; cfg->relocalization_enable = 0;
+    cfg->deltaA = 2; cfg->deltaR = 1; cfg->deltaP = 2;
+    cfg->edge_dis_th = 60; cfg->subgraph_edge_th = 20; cfg->subinterval = 30; cfg->graph_node_dimension = 30;
+    cfg->nearest_neighbor_vehicle_disth = 1.0; cfg->nearest_neighbor_pole_disth = 1.0;
+    cfg->max_local_graph_map_range = 60.0;
+    cfg->order_mode = 0; cfg->max_points = 1 << 20; cfg->map_capacity_log2 = 19; cfg->enable_graph = 1;
+}
+
+int sgs_preset(const char *name, sgs_config *cfg) {
+    if (!name || !cfg) return SGS_EINVAL;
+    sgs_default_config(cfg);
+    const std::string s(name);
+    // ros/launch/semgraph_slam_kitti.launch:12-60 (shared by the other launch files unless noted)
+    cfg->max_range = 100.0; cfg->min_range = 5.0; cfg->voxel_size = 1.0; cfg->max_points_per_voxel = 20;
+    cfg->initial_threshold = 2.0; cfg->min_motion_th = 0.1;
+    cfg->deltaA = 2.0; cfg->deltaR = 0.5; cfg->deltaP = 2.0;
+    cfg->edge_dis_th = 60.0; cfg->subgraph_edge_th = 20.0; cfg->subinterval = 30; cfg->graph_node_dimension = 30;
+    cfg->nearest_neighbor_vehicle_disth = 2.0; cfg->nearest_neighbor_pole_disth = 2.0;
+    cfg->max_local_graph_map_range = 100.0;
+    cfg->model_deviation_trans = 0.12; cfg->model_deviation_rot = 0.01; cfg->inlier_rate_th = 0.43;
+    if (s == "kitti" || s == "apollo" || s == "synthetic_hdl64") return SGS_OK;
+    if (s == "mulran") {  // semgraph_slam_mulran.launch:12,53
+        cfg->deskew = 1;
+        cfg->max_local_graph_map_range = 60.0;
+        return SGS_OK;
+    }
+    if (s == "relocalization") {  // semgraph_slam_relocalization.launch:13-15,59
+        cfg->max_range = 80.0;
+        cfg->relocalization_enable = 1;
+        cfg->inlier_rate_th = 0.37;
+        return SGS_OK;
+    }
+    if (s == "dense_128") {
+        cfg->max_points = 1 << 21;
+        cfg->map_capacity_log2 = 21;
+        return SGS_OK;
+    }
+    return SGS_EINVAL;
+}
+
+int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
+    if (!cfg_in || !out) return SGS_EINVAL;
+    *out = nullptr;
+    sgs_config cfg;
+    sgs_default_config(&cfg);
+    memcpy(&cfg, cfg_in, std::min<size_t>(cfg_in->size ? cfg_in->size : sizeof(sgs_config), sizeof(sgs_config)));
+    cfg.size = sizeof(sgs_config);
+    if (cfg.max_points_per_voxel < 1 || cfg.max_points_per_voxel > 255 || !(cfg.voxel_size > 0) || !(cfg.voxel_size_cluster > 0) ||
+        cfg.max_points < 1 || cfg.map_capacity_log2 < 8 || cfg.map_capacity_log2 > 26 || cfg.order_mode != 0)
+        return SGS_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SGS_EHIP;
+    if (hipSetDevice(device) != hipSuccess) return SGS_EHIP;
+    sgs_ctx *c = new sgs_ctx();
+    c->cfg = cfg;
+    c->device = device;
+    memset(&c->stats, 0, sizeof(c->stats));
+    c->stats.size = sizeof(sgs_stats);
+    c->N = cfg.max_points;
+    const size_t N = (size_t)c->N;
+    int r = SGS_OK;
+    auto bail = [&](int code) {
+        sgs_destroy(c);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(SGS_EHIP);
+    if ((r = dev_alloc(c, &c->in_f32, N * 4))) return bail(r);
+    if ((r = dev_alloc(c, &c->in_f64, N * 3))) return bail(r);
+    if ((r = dev_alloc(c, &c->in_label, N))) return bail(r);
+    if ((r = dev_alloc(c, &c->in_ts, N))) return bail(r);
+    CloudView *clouds[] = {&c->tmp, &c->cropped, &c->cluster, &c->ds, &c->src, &c->world, &c->aux};
+    for (CloudView *v : clouds)
+        if ((r = alloc_cloud(c, v, N))) return bail(r);
+    if ((r = dev_alloc(c, &c->flags, N))) return bail(r);
+    if ((r = dev_alloc(c, &c->blockcnt, N / 256 + 2))) return bail(r);
+    size_t Bmax = 1;
+    while (Bmax < 2 * N) Bmax <<= 1;
+    for (int k = 0; k < 2; ++k) {
+        if ((r = dev_alloc(c, &c->ds_table[k], Bmax))) return bail(r);
+        if ((r = dev_alloc(c, &c->ds_homebase[k], Bmax))) return bail(r);
+        if ((r = dev_alloc(c, &c->ds_blocksum[k], Bmax / 1024 + 2))) return bail(r);
+        if ((r = dev_alloc(c, &c->ds_sim[k], Bmax * 2))) return bail(r);
+        if ((r = dev_alloc(c, &c->ds_lay[k], Bmax * 2))) return bail(r);
+        if ((r = dev_alloc(c, &c->ds_order[k], N))) return bail(r);
+    }
+    if ((r = dev_alloc(c, &c->ds_index, N))) return bail(r);
+    if ((r = dev_alloc(c, &c->aux_n, 8))) return bail(r);
+    if ((r = dev_alloc(c, &c->map_slot_of, N))) return bail(r);
+    if ((r = dev_alloc(c, &c->map_next, N))) return bail(r);
+    if ((r = dev_alloc(c, &c->map_blockstat, ((size_t)1 << 26) / 256))) return bail(r);
+    if ((r = dev_alloc(c, &c->partials, (size_t)kIcpBlocks * kIcpSums))) return bail(r);
+    if ((r = dev_alloc(c, &c->out28, 32))) return bail(r);
+    if ((r = dev_alloc(c, &c->corr_tgt, N * 4))) return bail(r);
+    if ((r = dev_alloc(c, &c->corr_found, N))) return bail(r);
+    if ((r = dev_alloc(c, &c->st, 1))) return bail(r);
+    if (hipHostMalloc((void **)&c->st_host, sizeof(DevState), hipHostMallocDefault) != hipSuccess) return bail(SGS_ENOMEM);
+    if ((r = alloc_map(c, &c->map, cfg.map_capacity_log2))) return bail(r);
+    if ((r = graph_scratch_alloc(c->gs, c->N))) return bail(fail(c, r, "graph scratch allocation failed"));
+    if (hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream) != hipSuccess) return bail(SGS_EHIP);
+    launch_map_clear(c->stream, c->map.v, c->st);
+    for (int k = 0; k < 8; ++k)
+        if (hipEventCreate(&c->stage_ev[k]) != hipSuccess) return bail(SGS_EHIP);
+    c->stage_ev_ok = true;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(SGS_EHIP);
+    *out = c;
+    return SGS_OK;
+}
+
+void sgs_destroy(sgs_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) hipFree(p);
+    free_map(&c->map);
+    graph_scratch_free(c->gs);
+    if (c->st_host) hipHostFree(c->st_host);
+    for (auto &e : c->icp_events) {
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
+    if (c->stage_ev_ok)
+        for (int k = 0; k < 8; ++k) hipEventDestroy(c->stage_ev[k]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *sgs_last_error(const sgs_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int sgs_get_stats(sgs_ctx *c, sgs_stats *out) {
+    if (bad_ctx(c) || !out) return SGS_EINVAL;
+    const uint32_t sz = out->size ? std::min<uint32_t>(out->size, sizeof(sgs_stats)) : sizeof(sgs_stats);
+    c->stats.size = sz;
+    memcpy(out, &c->stats, sz);
+    return SGS_OK;
+}
+int sgs_reset_stats(sgs_ctx *c) {
+    if (bad_ctx(c)) return SGS_EINVAL;
+    memset(&c->stats, 0, sizeof(c->stats));
+    c->stats.size = sizeof(sgs_stats);
+    return SGS_OK;
+}
+int sgs_set_profiling(sgs_ctx *c, int enable) {
+    if (bad_ctx(c)) return SGS_EINVAL;
+    c->profiling = enable != 0;
+    return SGS_OK;
+}
+
+#define ENTER(c)                          \
+    if (bad_ctx(c)) return SGS_EINVAL;    \
+    if (hipSetDevice((c)->device) != hipSuccess) return fail((c), SGS_EHIP, "hipSetDevice failed")
+#define CHECK_N(c, n) \
+    if ((n) < 0 || (n) > (c)->N) return fail((c), (n) < 0 ? SGS_EINVAL : SGS_ECAPACITY, "n=%d outside [0, max_points=%d]", (n), (c)->N)
+
+int sgs_preprocess(sgs_ctx *c, const double *xyz, const int32_t *label, int n, double max_range, double min_range,
+                   double *out_xyz, int32_t *out_label, int out_cap, int *out_n) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && (!xyz || !label)) || !out_n) return fail(c, SGS_EINVAL, "null argument");
+    SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    PreParams p{};
+    p.crop = 1; p.max_range = max_range; p.min_range = min_range;
+    launch_preprocess(c->stream, nullptr, c->in_f64, c->in_label, nullptr, n, p, c->tmp, c->flags, c->blockcnt, c->aux, &c->aux_n[0]);
+    int m = 0, r;
+    if ((r = read_dev_int(c, &c->aux_n[0], &m))) return r;
+    *out_n = m;
+    const int k = std::min(m, out_cap);
+    if ((r = download_cloud(c, c->aux, k, out_xyz, out_label))) return r;
+    return m > out_cap ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", out_cap, m) : SGS_OK;
+}
+
+int sgs_correct_kitti(sgs_ctx *c, const double *xyz, int n, double *out_xyz) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if (n && (!xyz || !out_xyz)) return fail(c, SGS_EINVAL, "null argument");
+    SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    PreParams p{};
+    p.mode_kitti = 1;
+    const double a = (0.205 * M_PI) / 180.0;
+    p.sin_a = sin(a); p.cos_a = cos(a);
+    launch_preprocess(c->stream, nullptr, c->in_f64, nullptr, nullptr, n, p, c->tmp, c->flags, c->blockcnt, c->aux, &c->aux_n[0]);
+    return download_cloud(c, c->aux, n, out_xyz, nullptr);
+}
+
+int sgs_deskew(sgs_ctx *c, const double *xyz, const double *ts, int n, const double *start7, const double *finish7, double *out_xyz) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && (!xyz || !ts || !out_xyz)) || !start7 || !finish7) return fail(c, SGS_EINVAL, "null argument");
+    SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    SGS_HIP(c, hipMemcpyAsync(c->in_ts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    PreParams p{};
+    p.mode_deskew = 1;
+    rigid_log(compose(invert(rigid_from_pose7(start7)), rigid_from_pose7(finish7)), p.delta);
+    launch_preprocess(c->stream, nullptr, c->in_f64, nullptr, c->in_ts, n, p, c->tmp, c->flags, c->blockcnt, c->aux, &c->aux_n[0]);
+    return download_cloud(c, c->aux, n, out_xyz, nullptr);
+}
+
+int sgs_voxel_keys(sgs_ctx *c, const double *xyz, int n, double voxel_size, int32_t *keys_out) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && (!xyz || !keys_out)) || !(voxel_size > 0)) return fail(c, SGS_EINVAL, "bad argument");
+    if (n == 0) return SGS_OK;
+    SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    int32_t *keys_dev = (int32_t *)c->corr_tgt;  // N*4 doubles of scratch >= n*3 ints
+    launch_voxel_keys(c->stream, c->in_f64, n, voxel_size, keys_dev);
+    SGS_HIP(c, hipMemcpyAsync(keys_out, keys_dev, sizeof(int32_t) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SGS_HIP(c, hipStreamSynchronize(c->stream));
+    return SGS_OK;
+}
+
+int sgs_voxel_downsample(sgs_ctx *c, const double *xyz, const int32_t *label, int n, double voxel_size, double *out_xyz,
+                         int32_t *out_label, int32_t *out_index, int out_cap, int *out_n) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && (!xyz || !label)) || !out_n || !(voxel_size > 0)) return fail(c, SGS_EINVAL, "bad argument");
+    int r;
+    if ((r = upload_xyz(c, xyz, n, c->cropped, label))) return r;  // aux_n[0] = n
+    DsJob j = make_job(c, 0, c->cropped, &c->aux_n[0], voxel_size, c->aux, &c->aux_n[1], c->ds_index);
+    launch_downsample(c->stream, &j, 1, n, c->st);
+    int m = 0;
+    if (n == 0) { *out_n = 0; return SGS_OK; }
+    if ((r = read_dev_int(c, &c->aux_n[1], &m))) return r;
+    if ((r = sync_state(c))) return r;
+    if ((r = check_err_flags(c))) return r;
+    *out_n = m;
+    const int k = std::min(m, out_cap);
+    if ((r = download_cloud(c, c->aux, k, out_xyz, out_label))) return r;
+    if (out_index && k > 0) {
+        SGS_HIP(c, hipMemcpyAsync(out_index, c->ds_index, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+        SGS_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return m > out_cap ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", out_cap, m) : SGS_OK;
+}
+
+// ---- map ----
+int sgs_map_clear(sgs_ctx *c) {
+    ENTER(c);
+    launch_map_clear(c->stream, c->map.v, c->st);
+    return sync_state(c);
+}
+int sgs_map_empty(sgs_ctx *c, int *empty) {
+    ENTER(c);
+    if (!empty) return SGS_EINVAL;
+    *empty = c->map_live_host == 0 ? 1 : 0;
+    return SGS_OK;
+}
+static int map_add_common(sgs_ctx *c, const double *xyzl, int n, const double *pose7, bool prune) {
+    int r;
+    if ((r = maybe_rehash(c, n))) return r;
+    if ((r = upload_xyzl(c, xyzl, n, c->aux))) return r;  // aux_n[0] = n
+    const Rigid *T_dev = nullptr;
+    if (pose7) {
+        launch_icp_init(c->stream, c->st, rigid_from_pose7(pose7), 0, 0, 0, 0);  // parks the pose in st->T_total
+        T_dev = &c->st->T_total;
+    }
+    launch_map_add(c->stream, c->map.v, c->aux, &c->aux_n[0], n, T_dev, c->map_slot_of, c->map_next, c->world, c->st);
+    launch_map_sweep(c->stream, c->map.v, T_dev, nullptr, c->cfg.max_range, prune ? 1 : 0, c->map_blockstat, c->st);
+    if ((r = sync_state(c))) return r;
+    return check_err_flags(c);
+}
+int sgs_map_add_points(sgs_ctx *c, const double *xyzl, int n) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if (n && !xyzl) return fail(c, SGS_EINVAL, "null argument");
+    return map_add_common(c, xyzl, n, nullptr, false);
+}
+int sgs_map_update(sgs_ctx *c, const double *xyzl, int n, const double *pose7) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && !xyzl) || !pose7) return fail(c, SGS_EINVAL, "null argument");
+    return map_add_common(c, xyzl, n, pose7, true);
+}
+int sgs_map_prune(sgs_ctx *c, const double *origin3) {
+    ENTER(c);
+    if (!origin3) return fail(c, SGS_EINVAL, "null argument");
+    launch_map_sweep(c->stream, c->map.v, nullptr, origin3, c->cfg.max_range, 1, c->map_blockstat, c->st);
+    return sync_state(c);
+}
+int sgs_map_size(sgs_ctx *c, int *voxels, int *points) {
+    ENTER(c);
+    if (voxels) *voxels = c->map_live_host;
+    if (points) *points = c->map_points_host;
+    return SGS_OK;
+}
+static int map_download(sgs_ctx *c, std::vector<MapSlot> &slots, std::vector<float4> &pts) {
+    const size_t cap = (size_t)c->map.v.mask + 1;
+    slots.resize(cap);
+    pts.resize(cap * (size_t)c->map.v.cap);
+    SGS_HIP(c, hipMemcpyAsync(slots.data(), c->map.v.slots, cap * sizeof(MapSlot), hipMemcpyDeviceToHost, c->stream));
+    SGS_HIP(c, hipMemcpyAsync(pts.data(), c->map.v.pts, pts.size() * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    SGS_HIP(c, hipStreamSynchronize(c->stream));
+    return SGS_OK;
+}
+static inline void slot_point(const sgs_ctx *c, const MapSlot &e, const float4 &q, double *o) {
+    const K3 k = unpack_key(e.key);
+    o[0] = (double)k.x * c->map.v.voxel + (double)q.x;
+    o[1] = (double)k.y * c->map.v.voxel + (double)q.y;
+    o[2] = (double)k.z * c->map.v.voxel + (double)q.z;
+    int lab;
+    memcpy(&lab, &q.w, sizeof(int));
+    o[3] = (double)lab;
+}
+int sgs_map_pointcloud(sgs_ctx *c, double *xyzl, int cap, int *n) {
+    ENTER(c);
+    if (!n) return SGS_EINVAL;
+    std::vector<MapSlot> slots;
+    std::vector<float4> pts;
+    int r;
+    if ((r = map_download(c, slots, pts))) return r;
+    int m = 0;
+    for (size_t s = 0; s < slots.size(); ++s) {
+        if (slots[s].key == kEmptyKey || slots[s].key == kTombKey) continue;
+        for (uint32_t j = 0; j < slots[s].cnt; ++j) {
+            if (m < cap && xyzl) slot_point(c, slots[s], pts[s * (size_t)c->map.v.cap + j], xyzl + 4 * (size_t)m);
+            ++m;
+        }
+    }
+    *n = m;
+    return m > cap ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", cap, m) : SGS_OK;
+}
+int sgs_map_dump(sgs_ctx *c, int max_voxels, int32_t *keys, int32_t *counts, double *points, int *n_voxels) {
+    ENTER(c);
+    if (!n_voxels) return SGS_EINVAL;
+    std::vector<MapSlot> slots;
+    std::vector<float4> pts;
+    int r;
+    if ((r = map_download(c, slots, pts))) return r;
+    std::vector<size_t> live;
+    for (size_t s = 0; s < slots.size(); ++s)
+        if (slots[s].key != kEmptyKey && slots[s].key != kTombKey) live.push_back(s);
+    // packed keys are biased per axis, so their integer order is the (x,y,z) lexicographic order
+    std::sort(live.begin(), live.end(), [&](size_t a, size_t b) { return slots[a].key < slots[b].key; });
+    const int cap = c->map.v.cap;
+    const int nv = (int)std::min<size_t>(live.size(), (size_t)std::max(0, max_voxels));
+    for (int i = 0; i < nv; ++i) {
+        const MapSlot &e = slots[live[(size_t)i]];
+        const K3 k = unpack_key(e.key);
+        if (keys) { keys[3 * i] = k.x; keys[3 * i + 1] = k.y; keys[3 * i + 2] = k.z; }
+        if (counts) counts[i] = (int32_t)e.cnt;
+        if (points)
+            for (int j = 0; j < cap; ++j) {
+                double *o = points + ((size_t)i * cap + j) * 4;
+                if (j < (int)e.cnt) slot_point(c, e, pts[live[(size_t)i] * (size_t)cap + j], o);
+                else o[0] = o[1] = o[2] = o[3] = 0;
+            }
+    }
+    *n_voxels = (int)live.size();
+    return (int)live.size() > max_voxels ? fail(c, SGS_ECAPACITY, "output capacity %d < %zu", max_voxels, live.size()) : SGS_OK;
+}
+
+int sgs_map_get_correspondences(sgs_ctx *c, const double *xyzl, int n, double max_distance, double *src_xyzl,
+                                double *tgt_xyzl, int32_t *query_index, int cap, int *m_out) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && !xyzl) || !m_out) return fail(c, SGS_EINVAL, "null argument");
+    *m_out = 0;
+    if (n == 0) return SGS_OK;
+    int r;
+    if ((r = upload_xyzl(c, xyzl, n, c->aux))) return r;
+    launch_correspondences(c->stream, c->map.v, c->aux, n, max_distance, c->corr_tgt, c->corr_found);
+    std::vector<double> tgt((size_t)n * 4);
+    std::vector<int32_t> found((size_t)n);
+    SGS_HIP(c, hipMemcpyAsync(tgt.data(), c->corr_tgt, sizeof(double) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SGS_HIP(c, hipMemcpyAsync(found.data(), c->corr_found, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SGS_HIP(c, hipStreamSynchronize(c->stream));
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!found[(size_t)i]) continue;
+        if (m < cap) {
+            if (src_xyzl) memcpy(src_xyzl + 4 * (size_t)m, xyzl + 4 * (size_t)i, 4 * sizeof(double));
+            if (tgt_xyzl) memcpy(tgt_xyzl + 4 * (size_t)m, tgt.data() + 4 * (size_t)i, 4 * sizeof(double));
+            if (query_index) query_index[m] = i;
+        }
+        ++m;
+    }
+    *m_out = m;
+    return m > cap ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", cap, m) : SGS_OK;
+}
+
+int sgs_build_linear_system(sgs_ctx *c, const double *xyzl_world, int n, double max_distance, double kernel, double *out27,
+                            int *n_corr) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && !xyzl_world) || !out27) return fail(c, SGS_EINVAL, "null argument");
+    int r;
+    if ((r = upload_xyzl(c, xyzl_world, n, c->aux))) return r;  // aux_n[0] = n
+    launch_icp_init(c->stream, c->st, rigid_identity(), max_distance, kernel, 1, 1);
+    launch_icp_iteration(c->stream, c->map.v, c->aux, &c->aux_n[0], c->st, c->partials, false);
+    launch_linear_system_finish(c->stream, c->st, c->partials, c->out28);
+    double h[28];
+    SGS_HIP(c, hipMemcpyAsync(h, c->out28, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    SGS_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(out27, h, 27 * sizeof(double));
+    if (n_corr) *n_corr = (int)h[27];
+    return SGS_OK;
+}
+
+int sgs_register_frame(sgs_ctx *c, const double *xyzl, int n, const double *guess7, double max_corr, double kernel,
+                       double *out_pose7, int *iterations) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && !xyzl) || !guess7 || !out_pose7) return fail(c, SGS_EINVAL, "null argument");
+    int r;
+    if ((r = upload_xyzl(c, xyzl, n, c->aux))) return r;  // aux_n[0] = n
+    int iters = 0;
+    const Rigid guess = rigid_from_pose7(guess7);
+    if ((r = run_icp(c, c->aux, &c->aux_n[0], guess, max_corr, kernel, &iters))) return r;
+    if ((r = sync_state(c))) return r;
+    if (c->profiling) drain_icp_events(c, iters);
+    rigid_to_pose7(c->st_host->T_total, out_pose7);
+    if (iterations) *iterations = iters;
+    return SGS_OK;
+}
+
+// ---- cluster / graph ----
+int sgs_cluster_points(sgs_ctx *c, const double *xyz, const int32_t *label, int n, double dA, double dR, double dP,
+                       double *boxes, int box_cap, int *n_boxes, int32_t *point_cluster, int *n_fg, int *n_bg) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && (!xyz || !label)) || !n_boxes) return fail(c, SGS_EINVAL, "null argument");
+    int r;
+    if ((r = upload_xyz(c, xyz, n, c->aux, label))) return r;  // aux_n[0] = n
+    sgs_config cfg = c->cfg;
+    cfg.deltaA = dA; cfg.deltaR = dR; cfg.deltaP = dP;
+    std::vector<double> bx;
+    int nb = 0;
+    if ((r = graph_cluster(c->stream, c->gs, c->aux, &c->aux_n[0], n, cfg, &bx, &nb, point_cluster, n_fg, n_bg, &c->err))) return r;
+    *n_boxes = nb;
+    if (boxes) memcpy(boxes, bx.data(), sizeof(double) * 8 * (size_t)std::min(nb, box_cap));
+    return nb > box_cap ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", box_cap, nb) : SGS_OK;
+}
+
+int sgs_build_graph(sgs_ctx *c, const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
+                    double subgraph_edge_th, float *desc, double *edge_matrix, double *eigenvalues, int32_t *edges,
+                    double *edge_value, double *edge_weights, int edge_cap, int *n_edges, int32_t *tri_counts,
+                    double *triangles, int tri_cap, int *n_triangles, int32_t *class_counts3) {
+    ENTER(c);
+    if (nb < 0 || (nb && !boxes)) return fail(c, SGS_EINVAL, "bad argument");
+    return graph_build(c->stream, c->gs, boxes, nb, edge_dis_th, subinterval, dim, subgraph_edge_th, desc, edge_matrix,
+                       eigenvalues, edges, edge_value, edge_weights, edge_cap, n_edges, tri_counts, triangles, tri_cap,
+                       n_triangles, class_counts3, &c->err);
+}
+
+// ---- pipeline ----
+int sgs_process_scan(sgs_ctx *c, const double *xyz, const int32_t *label, int n, const double *ts, int is_kitti,
+                     sgs_scan_result *res) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if (n && (!xyz || !label)) return fail(c, SGS_EINVAL, "null argument");
+    SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (ts) SGS_HIP(c, hipMemcpyAsync(c->in_ts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    return process_scan_dev(c, nullptr, c->in_f64, c->in_label, n, ts ? c->in_ts : nullptr, is_kitti, res);
+}
+int sgs_process_scan_f32(sgs_ctx *c, const float *xyzi, const int32_t *label, int n, const double *ts, int is_kitti,
+                         sgs_scan_result *res) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if (n && (!xyzi || !label)) return fail(c, SGS_EINVAL, "null argument");
+    SGS_HIP(c, hipMemcpyAsync(c->in_f32, xyzi, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (ts) SGS_HIP(c, hipMemcpyAsync(c->in_ts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    return process_scan_dev(c, c->in_f32, nullptr, c->in_label, n, ts ? c->in_ts : nullptr, is_kitti, res);
+}
+int sgs_process_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *label_dev, int n, const double *ts_dev,
+                             int is_kitti, sgs_scan_result *res) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if (n && (!xyzi_dev || !label_dev)) return fail(c, SGS_EINVAL, "null argument");
+    return process_scan_dev(c, xyzi_dev, nullptr, label_dev, n, ts_dev, is_kitti, res);
+}
+int sgs_get_cloud(sgs_ctx *c, int which, double *xyz, int32_t *label, int cap, int *n) {
+    ENTER(c);
+    if (which < 0 || which > 3 || !n) return fail(c, SGS_EINVAL, "bad argument");
+    const CloudView v = which == 0 ? c->cropped : which == 1 ? c->cluster : which == 2 ? c->ds : c->src;
+    const int m = c->last_n[which + 1];
+    *n = m;
+    int r = download_cloud(c, v, std::min(m, cap), xyz, label);
+    if (r) return r;
+    return m > cap ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", cap, m) : SGS_OK;
+}
+int sgs_get_boxes(sgs_ctx *c, double *boxes, int cap, int *n) {
+    ENTER(c);
+    if (!n) return SGS_EINVAL;
+    const int m = (int)(c->last_boxes.size() / 8);
+    *n = m;
+    if (boxes) memcpy(boxes, c->last_boxes.data(), sizeof(double) * 8 * (size_t)std::min(m, cap));
+    return m > cap ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", cap, m) : SGS_OK;
+}
+int sgs_get_poses(sgs_ctx *c, double *poses7, int cap, int *n) {
+    ENTER(c);
+    if (!n) return SGS_EINVAL;
+    const int m = (int)c->poses.size();
+    *n = m;
+    for (int i = 0; i < m && i < cap && poses7; ++i) rigid_to_pose7(c->poses[(size_t)i], poses7 + 7 * (size_t)i);
+    return m > cap ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", cap, m) : SGS_OK;
+}
+int sgs_remap_labels(const uint32_t *raw, int n, int32_t *out) {
+    if (n < 0 || (n && (!raw || !out))) return SGS_EINVAL;
+    static const int kv[][2] = {{0, 0}, {1, 0}, {10, 1}, {11, 2}, {13, 5}, {15, 3}, {16, 5}, {18, 4}, {20, 5}, {30, 6}, {31, 7},
+                                {32, 8}, {40, 9}, {44, 10}, {48, 11}, {49, 12}, {50, 13}, {51, 14}, {52, 0}, {60, 9}, {70, 15},
+                                {71, 16}, {72, 17}, {80, 18}, {81, 19}, {99, 0}, {252, 20}, {253, 21}, {254, 22}, {255, 23},
+                                {256, 24}, {257, 24}, {258, 25}, {259, 24}};
+    static int32_t lut[65536];
+    static bool init = false;
+    if (!init) {
+        memset(lut, 0, sizeof(lut));
+        for (auto &p : kv) lut[p[0]] = p[1];
+        init = true;
+    }
+    for (int i = 0; i < n; ++i) out[i] = lut[raw[i] & 0xFFFFu];
+    return SGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Device-side data layout of one SG-SLAM context and the launch wrappers of every kernel.
+// Everything lives in HBM for the lifetime of the context; a scan touches only small host<->device
+// transfers (raw scan in, pose + counters out).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "sgs_math.h"
+
+namespace sgs {
+
+// ---- point clouds: fp64 SoA (exact: voxel keys must come from the very doubles the reference
+// would see), label int32 ----
+struct CloudView {
+    double *x, *y, *z;
+    int32_t *l;
+};
+
+// ---- voxel-downsample scratch table (one per grid), B = pow2ceil(2n) slots like the reference's
+// tsl::robin_map after reserve(n) so that "home" buckets match (F/Preprocessing.cpp:73-74) ----
+struct DsEntry {
+    unsigned long long key;  // packed voxel key or kEmptyKey
+    uint32_t minidx;         // smallest input index that fell into this voxel
+    uint32_t pad;
+};
+
+struct DsJob {
+    CloudView in;
+    const int32_t *n_in;  // device pointer to the input size
+    double voxel;
+    DsEntry *table;
+    int32_t *homebase;    // exclusive scan of the occupancy flags = emission position of each bucket
+    int32_t *blocksum;    // scan scratch
+    int32_t *sim, *lay;   // 2 ints per bucket each: robin-hood replay scratch
+    int32_t *order;       // emission position -> input index
+    CloudView out;
+    int32_t *out_index;   // optional
+    int32_t *n_out;       // device pointer to the output size
+};
+
+// ---- GPU-resident voxel hash map (F/VoxelHashMap.hpp:37-83) ----
+// open addressing, linear probing, slot == storage block.  16-byte slot header so one load gives
+// key + count; points are voxel-local fp32 offsets (x,y,z) + label bits, cap per voxel contiguous.
+struct MapSlot {
+    unsigned long long key;  // packed key, kEmptyKey or kTombKey
+    uint32_t cnt;            // points stored (<= cap)
+    int32_t head;            // per-batch pending list head (-1 outside sgs_map_add), see k_map.hip
+};
+struct MapView {
+    MapSlot *slots;
+    float4 *pts;      // [slot][cap]
+    double *first;    // [slot][3]: world coordinates of the voxel's oldest point (prune predicate)
+    uint32_t mask;    // capacity - 1
+    int32_t cap;      // max points per voxel
+    double voxel;
+};
+
+constexpr int kIcpSums = 20;  // 16 moment sums + n_corr + candidates + probes + spare
+constexpr int kIcpBlocks = 512;
+constexpr int kIcpThreads = 512;
+
+struct DevState {
+    // cloud sizes
+    int32_t n_in, n_c, n_d, n_s;
+    int32_t maxoff[3];
+    int32_t err_flags;  // bit0 key out of packable range, bit1 map table full, bit2 scan too large
+    // registration
+    Rigid guess, T_icp, T_total;
+    double max_corr, kernel_th;
+    int32_t icp_iter, icp_done, icp_max_iter, pad0;
+    long long icp_corr, icp_cand, icp_probe;
+    // map
+    int32_t map_live, map_tomb, map_points, pad1;
+    long long cas_retries;
+};
+
+enum { ERR_KEY_RANGE = 1, ERR_MAP_FULL = 2, ERR_SCAN_TOO_LARGE = 4 };
+
+// ---- k_pre.hip ----
+struct PreParams {
+    int mode_kitti;   // apply CorrectKITTIScan
+    int mode_deskew;  // apply DeSkewScan with `delta` (log of start^-1 * finish)
+    double delta[6];
+    int crop;         // apply the PreprocessSemantic predicate
+    double max_range, min_range;
+    double sin_a, cos_a;  // of the KITTI vertical angle offset, computed on the host
+};
+// in_f32 != nullptr: float32 stride-4 (x,y,z,i) input; else in_f64 stride-3
+void launch_preprocess(hipStream_t s, const float *in_f32, const double *in_f64, const int32_t *label,
+                       const double *timestamps, int n, const PreParams &p, CloudView tmp, int32_t *flags,
+                       int32_t *blockcnt, CloudView out, int32_t *n_out);
+void launch_voxel_keys(hipStream_t s, const double *xyz, int n, double voxel, int32_t *keys);
+
+// ---- k_downsample.hip ----
+void launch_downsample(hipStream_t s, const DsJob *jobs, int njobs, int n_upper, DevState *st);
+
+// ---- k_map.hip ----
+void launch_map_init(hipStream_t s, MapView m);
+// points in `in` (n from device pointer) are transformed by T (world = T * p) unless identity
+void launch_map_add(hipStream_t s, MapView m, CloudView in, const int32_t *n_ptr, int n_upper,
+                    const Rigid *T_dev /*nullable: identity*/, int32_t *slot_of, int32_t *next, CloudView world,
+                    DevState *st);
+// sweep = optional prune (origin = T_dev->t when T_dev != nullptr, else origin3_host) + census into st
+void launch_map_sweep(hipStream_t s, MapView m, const Rigid *T_dev, const double *origin3_host, double max_dist,
+                      int do_prune, int4 *blockstat, DevState *st);
+void launch_map_rehash(hipStream_t s, MapView from, MapView to, DevState *st);
+void launch_map_clear(hipStream_t s, MapView m, DevState *st);
+
+// ---- k_icp.hip ----
+void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max_corr, double kernel_th,
+                     int max_iter, int prior_world /*1: source already in world frame*/);
+// one Gauss-Newton iteration = fused correspondence search + linear-system reduction, then solve.
+// corr_* (optional) receive per-query results for sgs_map_get_correspondences.
+void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, const int32_t *n_ptr, DevState *st,
+                          double *partials, bool solve);
+void launch_icp_iteration_solve_only(hipStream_t s, DevState *st, double *partials);
+void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
+                            int32_t *found);
+void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out27_dev);
+
+}  // namespace sgs

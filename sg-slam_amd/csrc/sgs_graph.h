@@ -1,0 +1,82 @@
+// Instance clustering (F/SemanticCluster.cpp) and graph-descriptor construction (F/SemGraph.cpp):
+// device scratch + host entry points used by sgs_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "sgs.h"
+#include "sgs_device.h"
+
+namespace sgs {
+
+constexpr int kNumFgClasses = 5;  // 1 car, 4 truck, 5 other-vehicle, 16 trunk, 18 pole
+
+struct ClassParams {
+    int32_t n, start;              // points of this class: fg_order[start .. start+n)
+    int32_t length, width, height; // grid dims (F/SemanticCluster.cpp:37-39)
+    int32_t table_off, table_mask; // this class' slice of the cell table
+    int32_t n_labels;              // labels handed out (current_cluster)
+    double min_range, max_range;
+};
+
+struct CellSlot {
+    int32_t key;     // voxel_index, or INT_MIN when empty
+    int32_t count;   // points in the cell
+    int32_t start;   // offset of the cell's point list inside the class slice of cell_pts
+    int32_t cursor;
+};
+
+struct ClusterStat {
+    unsigned long long lo[3], hi[3];  // order-preserving encodings of the AABB doubles
+    int32_t count, first;             // points, smallest class-local point index
+};
+
+struct GraphScratch {
+    int N = 0;
+    int32_t *cat_blockcnt = nullptr;  // [nblocks][8]
+    int32_t *fg_order = nullptr;      // class-partitioned original indices
+    int32_t *fg_all = nullptr;        // all foreground points in original order
+    int32_t *bg_all = nullptr;        // background points in original order
+    int32_t *counts = nullptr;        // [8]: per class n (5), n_fg, n_bg
+    ClassParams *params = nullptr;    // [5]
+    int32_t *cell3 = nullptr;         // [N][4]: polar, range, azimuth, voxel_index per fg point (class order)
+    int32_t *cellslot = nullptr;      // [N]
+    int32_t *cell_pts = nullptr;      // [N]
+    CellSlot *table = nullptr;        // [4N]
+    int32_t *label = nullptr;         // [N] cluster label per fg point (class order)
+    int32_t *parent = nullptr;        // [N + 8] union-find over label values (per class slice, offset by start + class)
+    ClusterStat *stat = nullptr;      // [N + 8]
+    int32_t *pt_cluster = nullptr;    // [N] final cluster id per ORIGINAL point (0 = not foreground)
+    double *apr_range = nullptr;      // [N]
+    // graph
+    double *boxes_dev = nullptr;      // [kMaxNodes][8]
+    double *edge_dev = nullptr;       // [kMaxNodes^2]
+    int32_t *hist_dev = nullptr;      // [kMaxNodes][3*subinterval]
+    // host staging
+    ClassParams params_host[kNumFgClasses];
+    std::vector<float> last_desc;     // node descriptors of the last processed scan
+};
+
+constexpr int kMaxNodes = 1024;
+constexpr int kMaxHistCols = 3 * 256;
+
+int graph_scratch_alloc(GraphScratch &g, int N);
+void graph_scratch_free(GraphScratch &g);
+
+// ClusterPoints on the device cloud `in` (size from device pointer, upper bound n_upper).
+// boxes: 8 doubles per box in the reference's emission order.
+int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper, const sgs_config &cfg,
+                  std::vector<double> *boxes, int *n_boxes, int32_t *point_cluster_host, int *n_fg, int *n_bg,
+                  std::string *err);
+// cluster + graph for the pipeline (graph outputs are kept in g for later retrieval)
+int graph_process_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper,
+                       const sgs_config &cfg, std::vector<double> *boxes, int *n_boxes, std::string *err);
+int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
+                double subgraph_edge_th, float *desc, double *edge_matrix, double *eigenvalues, int32_t *edges,
+                double *edge_value, double *edge_weights, int edge_cap, int *n_edges, int32_t *tri_counts,
+                double *triangles, int tri_cap, int *n_triangles, int32_t *class_counts3, std::string *err);
+
+}  // namespace sgs

@@ -1,0 +1,220 @@
+// Host+device fp64 rigid-body maths for the SG-SLAM hot path (the subset of Sophus SE3d / Eigen the
+// reference touches: F/Registration.cpp:87,112,169; F/Deskew.cpp:41-44; F/Threshold.cpp:30;
+// P/SemGraphSLAM.cpp:61-63,79,157,165).  Compiled with -ffp-contract=off so the same expression
+// order yields the same bits on host and device.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#define SGS_HD __host__ __device__ inline
+
+namespace sgs {
+
+struct D3 {
+    double x, y, z;
+};
+SGS_HD D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+SGS_HD D3 add(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+SGS_HD D3 sub(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+SGS_HD D3 scale(double s, D3 a) { return D3{s * a.x, s * a.y, s * a.z}; }
+SGS_HD D3 crs(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// 3-vector reductions associate as x + (y + z), the order Eigen's unrolled redux uses.
+SGS_HD double sq3(D3 a) { return a.x * a.x + (a.y * a.y + a.z * a.z); }
+
+// rigid transform: unit quaternion (w,x,y,z) + translation
+struct Rigid {
+    double qw, qx, qy, qz;
+    D3 t;
+};
+SGS_HD Rigid rigid_identity() { return Rigid{1, 0, 0, 0, D3{0, 0, 0}}; }
+SGS_HD Rigid rigid_from_pose7(const double *p) { return Rigid{p[3], p[0], p[1], p[2], D3{p[4], p[5], p[6]}}; }
+SGS_HD void rigid_to_pose7(const Rigid &T, double *p) {
+    p[0] = T.qx; p[1] = T.qy; p[2] = T.qz; p[3] = T.qw;
+    p[4] = T.t.x; p[5] = T.t.y; p[6] = T.t.z;
+}
+SGS_HD D3 rotate(const Rigid &T, D3 p) {
+    const D3 qv{T.qx, T.qy, T.qz};
+    D3 uv = crs(qv, p);
+    uv = add(uv, uv);
+    return add(add(p, scale(T.qw, uv)), crs(qv, uv));
+}
+SGS_HD D3 apply(const Rigid &T, D3 p) { return add(rotate(T, p), T.t); }
+SGS_HD Rigid compose(const Rigid &a, const Rigid &b) {
+    Rigid r;
+    r.qw = a.qw * b.qw - a.qx * b.qx - a.qy * b.qy - a.qz * b.qz;
+    r.qx = a.qw * b.qx + a.qx * b.qw + a.qy * b.qz - a.qz * b.qy;
+    r.qy = a.qw * b.qy + a.qy * b.qw + a.qz * b.qx - a.qx * b.qz;
+    r.qz = a.qw * b.qz + a.qz * b.qw + a.qx * b.qy - a.qy * b.qx;
+    const double n = sqrt(r.qw * r.qw + r.qx * r.qx + r.qy * r.qy + r.qz * r.qz);
+    r.qw /= n; r.qx /= n; r.qy /= n; r.qz /= n;
+    r.t = add(a.t, rotate(a, b.t));
+    return r;
+}
+SGS_HD Rigid invert(const Rigid &T) {
+    Rigid r{T.qw, -T.qx, -T.qy, -T.qz, D3{0, 0, 0}};
+    const D3 rt = rotate(r, T.t);
+    r.t = D3{-rt.x, -rt.y, -rt.z};
+    return r;
+}
+
+constexpr double kTiny = 1e-10;
+
+// exp: tangent [v; w] -> rigid
+SGS_HD Rigid rigid_exp(const double *a) {
+    const D3 v{a[0], a[1], a[2]}, w{a[3], a[4], a[5]};
+    const double th2 = sq3(w);
+    double theta, im, re;
+    if (th2 < kTiny * kTiny) {
+        theta = 0;
+        const double th4 = th2 * th2;
+        im = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+        re = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+    } else {
+        theta = sqrt(th2);
+        const double h = 0.5 * theta;
+        im = sin(h) / theta;
+        re = cos(h);
+    }
+    Rigid T;
+    T.qw = re; T.qx = im * w.x; T.qy = im * w.y; T.qz = im * w.z;
+    const double n = sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
+    T.qw /= n; T.qx /= n; T.qy /= n; T.qz /= n;
+    // t = V v with V = I + c1 W + c2 W^2 (W = hat(w)); for theta -> 0, V = R
+    if (theta < kTiny) {
+        T.t = rotate(T, v);
+    } else {
+        const double c1 = (1.0 - cos(theta)) / th2;
+        const double c2 = (theta - sin(theta)) / (th2 * theta);
+        const D3 wv = crs(w, v);
+        const D3 wwv = crs(w, wv);
+        T.t = add(v, add(scale(c1, wv), scale(c2, wwv)));
+    }
+    return T;
+}
+// log: rigid -> tangent [v; w]
+SGS_HD void rigid_log(const Rigid &T, double *out) {
+    const double n2 = T.qx * T.qx + (T.qy * T.qy + T.qz * T.qz);
+    double k, theta;
+    if (n2 < kTiny * kTiny) {
+        k = 2.0 / T.qw - (2.0 / 3.0) * n2 / (T.qw * T.qw * T.qw);
+        theta = 2.0 * n2 / T.qw;
+    } else {
+        const double n = sqrt(n2);
+        const double at = (T.qw < 0) ? atan2(-n, -T.qw) : atan2(n, T.qw);
+        k = 2.0 * at / n;
+        theta = k * n;
+    }
+    const D3 w{k * T.qx, k * T.qy, k * T.qz};
+    double c;
+    if (fabs(theta) < kTiny) {
+        c = 1.0 / 12.0;
+    } else {
+        const double h = 0.5 * theta;
+        c = (1.0 - theta * cos(h) / (2.0 * sin(h))) / (theta * theta);
+    }
+    // v = (I - W/2 + c W^2) t
+    const D3 wt = crs(w, T.t);
+    const D3 wwt = crs(w, wt);
+    const D3 v = add(sub(T.t, scale(0.5, wt)), scale(c, wwt));
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+    out[3] = w.x; out[4] = w.y; out[5] = w.z;
+}
+SGS_HD double rigid_rotation_angle(const Rigid &T) {
+    const double n = sqrt(T.qx * T.qx + (T.qy * T.qy + T.qz * T.qz));
+    return 2.0 * atan2(n, fabs(T.qw));
+}
+
+// Symmetric 6x6 solve A x = b by LDL^T with diagonal pivoting; pivots at or below DBL_MIN are
+// treated as zero (pseudo-inverse), so an all-zero system yields x = 0 as Eigen's LDLT does
+// (F/Registration.cpp:111).  A is overwritten.
+SGS_HD void solve6(double A[6][6], const double *b, double *x) {
+    int tr[6];
+    bool zero = false;
+    for (int k = 0; k < 6; ++k) {
+        tr[k] = k;
+        if (zero) continue;
+        int p = k;
+        double best = fabs(A[k][k]);
+        for (int i = k + 1; i < 6; ++i) {
+            const double v = fabs(A[i][i]);
+            if (v > best) { best = v; p = i; }
+        }
+        tr[k] = p;
+        if (p != k) {
+            for (int j = 0; j < k; ++j) { const double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
+            for (int i = p + 1; i < 6; ++i) { const double t = A[i][k]; A[i][k] = A[i][p]; A[i][p] = t; }
+            { const double t = A[k][k]; A[k][k] = A[p][p]; A[p][p] = t; }
+            for (int i = k + 1; i < p; ++i) { const double t = A[i][k]; A[i][k] = A[p][i]; A[p][i] = t; }
+        }
+        double tmp[6];
+        for (int j = 0; j < k; ++j) tmp[j] = A[j][j] * A[k][j];
+        if (k > 0) {
+            double s = 0;
+            for (int j = 0; j < k; ++j) s += A[k][j] * tmp[j];
+            A[k][k] -= s;
+            for (int i = k + 1; i < 6; ++i) {
+                double s2 = 0;
+                for (int j = 0; j < k; ++j) s2 += A[i][j] * tmp[j];
+                A[i][k] -= s2;
+            }
+        }
+        const double akk = A[k][k];
+        if (k == 0 && !(fabs(akk) > 0.0)) { zero = true; continue; }
+        if (fabs(akk) > 0.0)
+            for (int i = k + 1; i < 6; ++i) A[i][k] /= akk;
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) y[i] = b[i];
+    for (int k = 0; k < 6; ++k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < i; ++j) y[i] -= A[i][j] * y[j];
+    for (int i = 0; i < 6; ++i) y[i] = (fabs(A[i][i]) > 2.2250738585072014e-308) ? y[i] / A[i][i] : 0.0;
+    for (int i = 5; i >= 0; --i)
+        for (int j = i + 1; j < 6; ++j) y[i] -= A[j][i] * y[j];
+    for (int k = 5; k >= 0; --k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+    for (int i = 0; i < 6; ++i) x[i] = y[i];
+}
+
+// ---- voxel keys ----
+struct K3 {
+    int32_t x, y, z;
+};
+SGS_HD K3 voxel_of(double x, double y, double z, double voxel_size) {
+    return K3{(int32_t)(x / voxel_size), (int32_t)(y / voxel_size), (int32_t)(z / voxel_size)};
+}
+// reference hash (core/Coreutils.h:40-45): used ONLY to reproduce tsl::robin_map's emission order
+SGS_HD uint32_t ref_hash(K3 k) {
+    return ((1u << 20) - 1u) & ((uint32_t)k.x * 73856093u ^ (uint32_t)k.y * 19349663u ^ (uint32_t)k.z * 83492791u);
+}
+constexpr int32_t kKeyBias = 1 << 20;  // keys are packed 21 bits per axis
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint64_t kTombKey = 0xFFFFFFFFFFFFFFFEull;
+SGS_HD bool key_in_range(K3 k) {
+    return k.x >= -kKeyBias && k.x < kKeyBias && k.y >= -kKeyBias && k.y < kKeyBias && k.z >= -kKeyBias && k.z < kKeyBias;
+}
+SGS_HD uint64_t pack_key(K3 k) {
+    return ((uint64_t)(uint32_t)(k.x + kKeyBias) << 42) | ((uint64_t)(uint32_t)(k.y + kKeyBias) << 21) |
+           (uint64_t)(uint32_t)(k.z + kKeyBias);
+}
+SGS_HD K3 unpack_key(uint64_t p) {
+    return K3{(int32_t)((p >> 42) & 0x1FFFFF) - kKeyBias, (int32_t)((p >> 21) & 0x1FFFFF) - kKeyBias,
+              (int32_t)(p & 0x1FFFFF) - kKeyBias};
+}
+// slot hash of the GPU-resident map (free choice: murmur3 finaliser on the packed key)
+SGS_HD uint32_t map_hash(uint64_t p) {
+    p ^= p >> 33;
+    p *= 0xff51afd7ed558ccdull;
+    p ^= p >> 33;
+    p *= 0xc4ceb9fe1a85ec53ull;
+    p ^= p >> 33;
+    return (uint32_t)p;
+}
+SGS_HD double semantic_weight(int label) {  // F/Registration.hpp:21-56
+    if (label == 16 || label == 18 || label == 19) return 1.2;
+    if (label >= 0 && label < 20) return 1.0;
+    return 0.0;
+}
+
+}  // namespace sgs
