@@ -107,7 +107,8 @@ def main():
         "algorithmic_bytes_per_launch": int(bytes_total / launches),
         "profiled_pass_ms_per_step": round(1e3 * elapsed_p / K, 4),
         "stage_ms_per_scan": {k: round(st.stage_ms[i] / max(1, st.scans), 4)
-                              for i, k in enumerate(["preprocess", "downsample", "icp", "map_update", "cluster_graph"])},
+                              for i, k in enumerate(["preprocess", "downsample", "icp", "map_update", "cluster_graph_stream2",
+                                                     "host_graph_finish", "host_call_total", "host_icp_loop"])},
     }
     out = {
         "metric": "scans/sec (120k-pt HDL-64 scan-to-map ICP)", "value": round(value, 2), "unit": "scans/s",
@@ -149,8 +150,10 @@ def main():
         out["cpu_baseline"] = {"value": round(m / t_cpu, 2), "unit": "scans/s", "cores": cores, "kind": "port",
                                "sample": f"the same first {W}+{m} synthetic scans (warm-up + timed) through the oracle restatement, "
                                          f"OpenMP where the reference uses TBB; timed scans {W}..{W + m - 1}"}
+        oc, gc = np.array(ocounts), counts[:W + m]
         out["parity"] = {"scans_checked": W + m, "max_pose_diff_m": worst_t, "max_pose_diff_rad": worst_r,
-                         "counts_equal": bool(np.array_equal(np.array(ocounts), counts[:W + m]))}
+                         "cloud_and_map_sizes_equal": bool(np.array_equal(oc[:, [0, 1, 2, 3, 5]], gc[:, [0, 1, 2, 3, 5]])),
+                         "max_icp_iteration_diff": int(np.abs(oc[:, 4] - gc[:, 4]).max())}
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.close()

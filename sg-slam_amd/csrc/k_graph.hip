@@ -72,21 +72,37 @@ __global__ __launch_bounds__(kBlock) void route_count_kernel(CloudView in, const
 }
 
 // exclusive per-category prefix over blocks (in place) + totals + class parameters
-__global__ void route_totals_kernel(int32_t *__restrict__ blockcnt, int nblocks, int32_t *__restrict__ counts,
-                                    ClassParams *__restrict__ params) {
+__global__ __launch_bounds__(kBlock) void route_totals_kernel(int32_t *__restrict__ blockcnt, int nblocks,
+                                                              int32_t *__restrict__ counts, ClassParams *__restrict__ params) {
     __shared__ int tot[8];
-    const int k = threadIdx.x;
-    if (k < 7) {
-        int run = 0;
-        for (int b = 0; b < nblocks; ++b) {
+    __shared__ int part[kBlock];
+    const int per = (nblocks + kBlock - 1) / kBlock;
+    const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
+    for (int k = 0; k < 7; ++k) {
+        int sum = 0;
+        for (int b = b0; b < b1; ++b) sum += blockcnt[b * 8 + k];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int t = 0; t < kBlock; ++t) {
+                const int v = part[t];
+                part[t] = run;
+                run += v;
+            }
+            tot[k] = run;
+            counts[k] = run;
+        }
+        __syncthreads();
+        int run = part[threadIdx.x];
+        for (int b = b0; b < b1; ++b) {
             const int v = blockcnt[b * 8 + k];
             blockcnt[b * 8 + k] = run;
             run += v;
         }
-        tot[k] = run;
-        counts[k] = run;
+        __syncthreads();
     }
-    __syncthreads();
+    const int k = threadIdx.x;
     if (k == 0) {
         int start = 0;
         for (int c = 0; c < kNumFgClasses; ++c) {
@@ -467,41 +483,95 @@ __global__ __launch_bounds__(128) void graph_edges_kernel(const double *__restri
     for (int k = threadIdx.x; k < cols; k += blockDim.x) hist[(size_t)i * cols + k] = s_hist[k];
 }
 
-// cyclic Jacobi eigen-decomposition of a symmetric matrix (host; N is tens of nodes)
+// Symmetric eigen-decomposition on the host (N is tens of nodes): Householder tridiagonalisation with
+// explicit accumulation of Q, then implicit symmetric QR steps with Wilkinson shifts (Golub & Van Loan
+// 8.3), rotations applied to the columns of Q.  Eigenvalues ascending like SelfAdjointEigenSolver.
 void jacobi_eig(int n, std::vector<double> &a, std::vector<double> &evals, std::vector<double> &evecs) {
     evecs.assign((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) evecs[(size_t)i * n + i] = 1.0;
     auto A = [&](int i, int j) -> double & { return a[(size_t)i * n + j]; };
-    auto V = [&](int i, int j) -> double & { return evecs[(size_t)i * n + j]; };
-    for (int sweep = 0; sweep < 100; ++sweep) {
-        double off = 0;
-        for (int p = 0; p < n; ++p)
-            for (int q = p + 1; q < n; ++q) off += A(p, q) * A(p, q);
-        if (off < 1e-30) break;
-        for (int p = 0; p < n; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A(p, q);
-                if (std::fabs(apq) < 1e-300) continue;
-                const double theta = (A(q, q) - A(p, p)) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < n; ++k) {
-                    const double akp = A(k, p), akq = A(k, q);
-                    A(k, p) = cs * akp - sn * akq;
-                    A(k, q) = sn * akp + cs * akq;
+    std::vector<double> vt((size_t)n * n, 0.0);  // transposed eigenvector matrix: row k = eigenvector k
+    for (int i = 0; i < n; ++i) vt[(size_t)i * n + i] = 1.0;
+    std::vector<double> v((size_t)n), pvec((size_t)n), w((size_t)n), sacc_r((size_t)n);
+    for (int k = 0; k + 2 < n; ++k) {
+        double tail2 = 0;
+        for (int i = k + 2; i < n; ++i) tail2 += A(i, k) * A(i, k);
+        if (tail2 == 0.0) continue;  // column already tridiagonal
+        const double x0 = A(k + 1, k);
+        const double alpha = -std::copysign(std::sqrt(x0 * x0 + tail2), x0);
+        for (int i = k + 1; i < n; ++i) v[(size_t)i] = A(i, k);
+        v[(size_t)k + 1] -= alpha;
+        double vn2 = 0;
+        for (int i = k + 1; i < n; ++i) vn2 += v[(size_t)i] * v[(size_t)i];
+        if (vn2 == 0.0) continue;
+        const double beta = 2.0 / vn2;
+        for (int i = k + 1; i < n; ++i) {
+            double sacc = 0;
+            for (int j = k + 1; j < n; ++j) sacc += A(i, j) * v[(size_t)j];
+            pvec[(size_t)i] = beta * sacc;
+        }
+        double kk = 0;
+        for (int i = k + 1; i < n; ++i) kk += v[(size_t)i] * pvec[(size_t)i];
+        kk *= 0.5 * beta;
+        for (int i = k + 1; i < n; ++i) w[(size_t)i] = pvec[(size_t)i] - kk * v[(size_t)i];
+        for (int i = k + 1; i < n; ++i)
+            for (int j = k + 1; j < n; ++j) A(i, j) -= v[(size_t)i] * w[(size_t)j] + w[(size_t)i] * v[(size_t)j];
+        A(k + 1, k) = A(k, k + 1) = alpha;
+        for (int i = k + 2; i < n; ++i) A(i, k) = A(k, i) = 0.0;
+        std::fill(sacc_r.begin(), sacc_r.end(), 0.0);
+        for (int j = k + 1; j < n; ++j) {
+            const double vj = v[(size_t)j];
+            const double *row = &vt[(size_t)j * n];
+            for (int r = 0; r < n; ++r) sacc_r[(size_t)r] += row[r] * vj;
+        }
+        for (int j = k + 1; j < n; ++j) {
+            const double vj = beta * v[(size_t)j];
+            double *row = &vt[(size_t)j * n];
+            for (int r = 0; r < n; ++r) row[r] -= sacc_r[(size_t)r] * vj;
+        }
+    }
+    std::vector<double> d((size_t)n), e((size_t)std::max(n, 1), 0.0);
+    for (int i = 0; i < n; ++i) d[(size_t)i] = A(i, i);
+    for (int i = 0; i + 1 < n; ++i) e[(size_t)i] = A(i + 1, i);
+    const double eps = 2.220446049250313e-16;
+    for (int hi = n - 1; hi > 0; --hi) {
+        for (int iter = 0; iter < 200; ++iter) {
+            if (std::fabs(e[(size_t)hi - 1]) <= eps * (std::fabs(d[(size_t)hi - 1]) + std::fabs(d[(size_t)hi]))) {
+                e[(size_t)hi - 1] = 0.0;
+                break;
+            }
+            int lo = hi - 1;
+            while (lo > 0 && std::fabs(e[(size_t)lo - 1]) > eps * (std::fabs(d[(size_t)lo - 1]) + std::fabs(d[(size_t)lo]))) --lo;
+            const double delta = 0.5 * (d[(size_t)hi - 1] - d[(size_t)hi]);
+            const double eh = e[(size_t)hi - 1];
+            const double denom = delta + std::copysign(std::hypot(delta, eh), delta == 0.0 ? 1.0 : delta);
+            const double mu = d[(size_t)hi] - eh * eh / denom;
+            double x = d[(size_t)lo] - mu, z = e[(size_t)lo];
+            for (int k = lo; k < hi; ++k) {
+                const double r = std::hypot(x, z);
+                const double c = r == 0.0 ? 1.0 : x / r, sn = r == 0.0 ? 0.0 : -z / r;
+                if (k > lo) e[(size_t)k - 1] = r;
+                const double aa = d[(size_t)k], bb = e[(size_t)k], gg = d[(size_t)k + 1];
+                d[(size_t)k] = c * c * aa - 2.0 * c * sn * bb + sn * sn * gg;
+                d[(size_t)k + 1] = sn * sn * aa + 2.0 * c * sn * bb + c * c * gg;
+                e[(size_t)k] = c * sn * (aa - gg) + (c * c - sn * sn) * bb;
+                if (k < hi - 1) {
+                    z = -sn * e[(size_t)k + 1];
+                    e[(size_t)k + 1] = c * e[(size_t)k + 1];
+                    x = e[(size_t)k];
                 }
-                for (int k = 0; k < n; ++k) {
-                    const double apk = A(p, k), aqk = A(q, k);
-                    A(p, k) = cs * apk - sn * aqk;
-                    A(q, k) = sn * apk + cs * aqk;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double vkp = V(k, p), vkq = V(k, q);
-                    V(k, p) = cs * vkp - sn * vkq;
-                    V(k, q) = sn * vkp + cs * vkq;
+                double *rk = &vt[(size_t)k * n], *rk1 = &vt[(size_t)(k + 1) * n];
+                for (int rr = 0; rr < n; ++rr) {
+                    const double qk = rk[rr], qk1 = rk1[rr];
+                    rk[rr] = c * qk - sn * qk1;
+                    rk1[rr] = sn * qk + c * qk1;
                 }
             }
+        }
     }
+    for (int i = 0; i < n; ++i) A(i, i) = d[(size_t)i];
+    for (int r = 0; r < n; ++r)
+        for (int k = 0; k < n; ++k) evecs[(size_t)r * n + k] = vt[(size_t)k * n + r];
     evals.resize((size_t)n);
     for (int i = 0; i < n; ++i) evals[(size_t)i] = A(i, i);
     // ascending order, columns permuted alongside (SelfAdjointEigenSolver convention)
@@ -541,6 +611,7 @@ int graph_scratch_alloc(GraphScratch &g, int N) {
               galloc(&g.parent, n + 16) && galloc(&g.stat, n + 16) && galloc(&g.pt_cluster, n) &&
               galloc(&g.boxes_dev, (size_t)kMaxNodes * 8) && galloc(&g.edge_dev, (size_t)kMaxNodes * kMaxNodes) &&
               galloc(&g.hist_dev, (size_t)kMaxNodes * kMaxHistCols);
+    if (ok) ok = hipHostMalloc((void **)&g.pinned, 1024, hipHostMallocDefault) == hipSuccess;
     return ok ? SGS_OK : SGS_ENOMEM;
 }
 
@@ -549,21 +620,19 @@ void graph_scratch_free(GraphScratch &g) {
                   g.table, g.label, g.parent, g.stat, g.pt_cluster, g.boxes_dev, g.edge_dev, g.hist_dev};
     for (void *p : ps)
         if (p) hipFree(p);
+    if (g.pinned) hipHostFree(g.pinned);
     g = GraphScratch();
 }
 
-int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper, const sgs_config &cfg,
-                  std::vector<double> *boxes, int *n_boxes, int32_t *point_cluster_host, int *n_fg, int *n_bg,
-                  std::string *err) {
-    if (boxes) boxes->clear();
-    if (n_boxes) *n_boxes = 0;
-    if (n_fg) *n_fg = 0;
-    if (n_bg) *n_bg = 0;
+// All cluster kernels + the small async read-back of counts / class parameters; no host sync.
+int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper,
+                          const sgs_config &cfg, std::string *err) {
+    g.enqueued_upper = n_upper;
     if (n_upper <= 0) return SGS_OK;
     if (!(cfg.deltaA > 0) || !(cfg.deltaR > 0) || !(cfg.deltaP > 0)) return gfail(err, SGS_EINVAL, "cluster deltas must be positive");
     const int nb = (n_upper + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(route_count_kernel, dim3(nb), dim3(kBlock), 0, s, in, n_ptr, g.cat_blockcnt, g.pt_cluster);
-    hipLaunchKernelGGL(route_totals_kernel, dim3(1), dim3(64), 0, s, g.cat_blockcnt, nb, g.counts, g.params);
+    hipLaunchKernelGGL(route_totals_kernel, dim3(1), dim3(kBlock), 0, s, g.cat_blockcnt, nb, g.counts, g.params);
     hipLaunchKernelGGL(route_scatter_kernel, dim3(nb), dim3(kBlock), 0, s, in, n_ptr, g.cat_blockcnt, g.params, g.fg_order,
                        g.fg_all, g.bg_all);
     hipLaunchKernelGGL(stat_init_kernel, dim3((n_upper + 16 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g.stat, n_upper + 16);
@@ -578,23 +647,40 @@ int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n
                        g.cellslot, g.cell_pts, g.table, g.label, g.parent);
     hipLaunchKernelGGL(cluster_stats_kernel, dim3(nb), dim3(kBlock), 0, s, in, g.params, g.counts, g.fg_order, g.label,
                        g.parent, g.stat, g.pt_cluster);
-    int32_t counts[8];
-    if (hipMemcpyAsync(counts, g.counts, sizeof(counts), hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipMemcpyAsync(g.params_host, g.params, sizeof(ClassParams) * kNumFgClasses, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess)
+    // counts (8 ints) and params (5 structs) land in one pinned block
+    if (hipMemcpyAsync(g.pinned, g.counts, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(g.pinned + 64, g.params, sizeof(ClassParams) * kNumFgClasses, hipMemcpyDeviceToHost, s) != hipSuccess)
         return gfail(err, SGS_EHIP, "cluster: device error");
+    return SGS_OK;
+}
+
+// Waits for the cluster kernels, reads the per-cluster statistics back in one copy and emits the boxes
+// in the reference's order.
+int graph_cluster_finish(hipStream_t s, GraphScratch &g, const int32_t *n_ptr, std::vector<double> *boxes, int *n_boxes,
+                         int32_t *point_cluster_host, int *n_fg, int *n_bg, std::string *err) {
+    if (boxes) boxes->clear();
+    if (n_boxes) *n_boxes = 0;
+    if (n_fg) *n_fg = 0;
+    if (n_bg) *n_bg = 0;
+    if (g.enqueued_upper <= 0) return SGS_OK;
+    if (hipStreamSynchronize(s) != hipSuccess) return gfail(err, SGS_EHIP, "cluster: device error");
+    int32_t counts[8];
+    memcpy(counts, g.pinned, sizeof(counts));
+    memcpy(g.params_host, g.pinned + 64, sizeof(ClassParams) * kNumFgClasses);
     if (n_fg) *n_fg = counts[5];
     if (n_bg) *n_bg = counts[6];
     int total = 0;
     static const int kClassLabel[kNumFgClasses] = {1, 1, 1, 2, 3};  // :311-322
-    std::vector<ClusterStat> st;
+    const size_t nstat = (size_t)counts[5] + kNumFgClasses + 1;
+    std::vector<ClusterStat> &all = g.stat_host;
+    all.resize(nstat);
+    if (counts[5] > 0 && (hipMemcpyAsync(all.data(), g.stat, sizeof(ClusterStat) * nstat, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                          hipStreamSynchronize(s) != hipSuccess))
+        return gfail(err, SGS_EHIP, "cluster: device error");
     for (int c = 0; c < kNumFgClasses; ++c) {
         const ClassParams &p = g.params_host[c];
         if (p.n <= 0 || p.n_labels <= 0) continue;
-        st.resize((size_t)p.n_labels);
-        if (hipMemcpyAsync(st.data(), g.stat + p.start + c + 1, sizeof(ClusterStat) * (size_t)p.n_labels, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess)
-            return gfail(err, SGS_EHIP, "cluster: device error");
+        const ClusterStat *st = all.data() + p.start + c + 1;
         // replay histcounts[...] insertion (:278-304): keys enter in order of first appearance
         std::vector<int> ids;
         for (int v = 1; v <= p.n_labels; ++v)
@@ -631,6 +717,14 @@ int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n
             return gfail(err, SGS_EHIP, "cluster: device error");
     }
     return SGS_OK;
+}
+
+int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper, const sgs_config &cfg,
+                  std::vector<double> *boxes, int *n_boxes, int32_t *point_cluster_host, int *n_fg, int *n_bg,
+                  std::string *err) {
+    int r = graph_cluster_enqueue(s, g, in, n_ptr, n_upper, cfg, err);
+    if (r) return r;
+    return graph_cluster_finish(s, g, n_ptr, boxes, n_boxes, point_cluster_host, n_fg, n_bg, err);
 }
 
 int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
@@ -738,9 +832,10 @@ int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, dou
     return SGS_OK;
 }
 
-int graph_process_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper,
-                       const sgs_config &cfg, std::vector<double> *boxes, int *n_boxes, std::string *err) {
-    int r = graph_cluster(s, g, in, n_ptr, n_upper, cfg, boxes, n_boxes, nullptr, nullptr, nullptr, err);
+int graph_finish_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, const sgs_config &cfg,
+                      std::vector<double> *boxes, int *n_boxes, std::string *err) {
+    (void)in;
+    int r = graph_cluster_finish(s, g, n_ptr, boxes, n_boxes, nullptr, nullptr, nullptr, err);
     if (r) return r;
     const int nb = *n_boxes;
     if (nb == 0) return SGS_OK;

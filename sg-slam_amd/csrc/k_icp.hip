@@ -167,27 +167,20 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(MapView m, 
         double sum = 0.0;
 #pragma unroll
         for (int w = 0; w < kIcpThreads / 64; ++w) sum += red[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kIcpSums + threadIdx.x] = sum;
+        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sum;  // [scalar][block]: the fold reads rows
     }
 }
 
-// fixed-order fold of the per-block partials: 20 scalars x 12 segments, then 12 -> 1
-constexpr int kFoldSegs = 12;
+// fixed-order fold of the per-block partials ([scalar][block] layout): each wave folds whole rows
+// with independent coalesced loads + a shuffle tree, so the result is bit-reproducible
 __device__ inline void fold_partials(const double *__restrict__ partials, int nblocks, double *out /*shared [kIcpSums]*/) {
-    __shared__ double seg[kFoldSegs][kIcpSums];
-    const int t = threadIdx.x;
-    if (t < kFoldSegs * kIcpSums) {
-        const int sc = t % kIcpSums, sg = t / kIcpSums;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int sc = wave; sc < kIcpSums; sc += nwaves) {
         double sum = 0.0;
-        for (int b = sg; b < nblocks; b += kFoldSegs) sum += partials[(size_t)b * kIcpSums + sc];
-        seg[sg][sc] = sum;
-    }
-    __syncthreads();
-    if (t < kIcpSums) {
-        double sum = 0.0;
+        for (int b = lane; b < nblocks; b += 64) sum += partials[(size_t)sc * nblocks + b];
 #pragma unroll
-        for (int g = 0; g < kFoldSegs; ++g) sum += seg[g][t];
-        out[t] = sum;
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        if (lane == 0) out[sc] = sum;
     }
     __syncthreads();
 }
@@ -213,16 +206,20 @@ __device__ inline void normal_equations(const double *S, double A[6][6], double 
     for (int i = 0; i < 6; ++i) b[i] = S[10 + i];
 }
 
-__global__ __launch_bounds__(256) void icp_solve_kernel(DevState *st, const double *__restrict__ partials, int nblocks) {
+// mailbox: 4 ints in host-pinned, device-mapped memory {iterations finished, done, -, -}; the host
+// polls it instead of issuing a copy + stream sync per chunk of iterations
+__global__ __launch_bounds__(256) void icp_solve_kernel(DevState *st, const double *__restrict__ partials, int nblocks,
+                                                        int32_t *mailbox) {
     if (st->icp_done) return;
     __shared__ double S[kIcpSums];
     fold_partials(partials, nblocks, S);
     if (threadIdx.x != 0) return;
     double A[6][6], b[6], rhs[6], x[6];
     normal_equations(S, A, b);
+#pragma unroll
     for (int i = 0; i < 6; ++i) rhs[i] = -b[i];
-    solve6(A, rhs, x);
-    const Rigid est = rigid_exp(x);
+    solve6_static(A, rhs, x);
+    const Rigid est = rigid_exp_small(x);
     const Rigid T_icp = compose(est, st->T_icp);
     st->T_icp = T_icp;
     st->T_total = compose(T_icp, st->guess);
@@ -231,11 +228,17 @@ __global__ __launch_bounds__(256) void icp_solve_kernel(DevState *st, const doub
     st->icp_probe += (long long)S[18];
     const int it = st->icp_iter + 1;
     st->icp_iter = it;
-    double lg[6];
-    rigid_log(est, lg);
+    // estimation.log().norm() (F/Registration.cpp:169): log(exp(x)) == x for |omega| < pi, so the
+    // 6-vector norm of the update itself is the termination quantity
     double nn = 0.0;
-    for (int i = 0; i < 6; ++i) nn += lg[i] * lg[i];
-    if (sqrt(nn) < 0.0001 || it >= st->icp_max_iter) st->icp_done = 1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
+    const int done = (sqrt(nn) < 0.0001 || it >= st->icp_max_iter) ? 1 : 0;
+    if (done) st->icp_done = 1;
+    if (mailbox) {
+        __hip_atomic_store(&mailbox[0], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mailbox[1], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ __launch_bounds__(256) void icp_finish_kernel(DevState *st, const double *__restrict__ partials, int nblocks,
@@ -294,13 +297,13 @@ void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max
 }
 
 void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, const int32_t *n_ptr, DevState *st, double *partials,
-                          bool solve) {
+                          bool solve, int32_t *mailbox) {
     hipLaunchKernelGGL(icp_accumulate_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, n_ptr, st, partials);
-    if (solve) hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, st, partials, kIcpBlocks);
+    if (solve) hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, st, partials, kIcpBlocks, mailbox);
 }
 
-void launch_icp_iteration_solve_only(hipStream_t s, DevState *st, double *partials) {
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, st, partials, kIcpBlocks);
+void launch_icp_iteration_solve_only(hipStream_t s, DevState *st, double *partials, int32_t *mailbox) {
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, st, partials, kIcpBlocks, mailbox);
 }
 
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out28_dev) {

@@ -116,24 +116,22 @@ __global__ __launch_bounds__(kBlock) void map_prune_kernel(MapView m, const Rigi
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
     int live = 0, tomb = 0, pts = 0;
     if (s <= m.mask) {
-        const MapSlot e = m.slots[s];
-        if (e.key == kTombKey) {
-            tomb = 1;
-        } else if (e.key != kEmptyKey) {
-            bool kill = false;
-            if (do_prune) {
-                const D3 o = T_dev ? T_dev->t : origin_host;
-                const D3 f{m.first[3 * (size_t)s], m.first[3 * (size_t)s + 1], m.first[3 * (size_t)s + 2]};
-                kill = sq3(sub(f, o)) > max_d2;
-            }
-            if (kill) {
-                m.slots[s].key = kTombKey;
-                m.slots[s].cnt = 0;
-                tomb = 1;
-            } else {
-                live = 1;
-                pts = (int)e.cnt;
-            }
+        const ulonglong2 raw = reinterpret_cast<const ulonglong2 *>(m.slots)[s];
+        const unsigned long long key = raw.x;
+        const int cnt = (int)(uint32_t)(raw.y & 0xFFFFFFFFull);
+        const bool valid = key != kTombKey && key != kEmptyKey;
+        bool kill = false;
+        if (valid && do_prune) {
+            const D3 o = T_dev ? T_dev->t : origin_host;
+            const D3 f{m.first[3 * (size_t)s], m.first[3 * (size_t)s + 1], m.first[3 * (size_t)s + 2]};
+            kill = sq3(sub(f, o)) > max_d2;
+        }
+        live = (valid && !kill) ? 1 : 0;
+        tomb = (key == kTombKey || kill) ? 1 : 0;
+        pts = live ? cnt : 0;
+        if (kill) {
+            // key = TOMB, cnt = 0, head = -1 in one 16-byte store
+            reinterpret_cast<ulonglong2 *>(m.slots)[s] = make_ulonglong2(kTombKey, 0xFFFFFFFF00000000ull);
         }
     }
     __shared__ int red[3][kBlock / 64];

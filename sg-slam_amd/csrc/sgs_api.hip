@@ -5,11 +5,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sgs.h"
@@ -29,12 +34,67 @@ struct MapBuf {
     int log2cap = 0;
 };
 
+// One helper thread per context: it owns the second stream's host work (wait for the cluster kernels,
+// read the statistics back, order the boxes, launch the graph kernel, eigen-decompose) so that this
+// runs while the calling thread drives the Gauss-Newton loop on the first stream.
+struct GraphWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, busy = false, quit = false;
+    int rc = 0;
+    void start(int device) {
+        th = std::thread([this, device] {
+            hipSetDevice(device);
+            std::unique_lock<std::mutex> lk(m);
+            while (true) {
+                cv.wait(lk, [this] { return has_job || quit; });
+                if (quit) return;
+                has_job = false;
+                std::function<int()> f = std::move(job);
+                lk.unlock();
+                const int r = f();
+                lk.lock();
+                rc = r;
+                busy = false;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<int()> f) {
+        std::lock_guard<std::mutex> lk(m);
+        job = std::move(f);
+        has_job = true;
+        busy = true;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return !busy; });
+        return rc;
+    }
+    void stop() {
+        if (!th.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+            cv.notify_all();
+        }
+        th.join();
+    }
+};
+
 }  // namespace
 
 struct sgs_ctx {
     sgs_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // instance clustering + graph run here, concurrently with the ICP loop
+    hipEvent_t ev_ds = nullptr, ev_g0 = nullptr, ev_g1 = nullptr;
+    int32_t *mailbox = nullptr;      // host-pinned, device-mapped: {icp iterations finished, done}
+    int32_t *mailbox_dev = nullptr;
     std::string err;
     std::vector<void *> allocs;
     int N = 0;  // max points per scan
@@ -66,6 +126,9 @@ struct sgs_ctx {
     DevState *st_host = nullptr;  // pinned
     // cluster / graph
     GraphScratch gs;
+    GraphWorker gworker;
+    std::string gerr;
+    int job_n_boxes = 0;
 
     // host-side SLAM state (P/SemGraphSLAM.hpp:105-111, F/Threshold.hpp:45-52)
     std::vector<Rigid> poses;
@@ -87,6 +150,10 @@ struct sgs_ctx {
 };
 
 namespace {
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int fail(sgs_ctx *c, int code, const char *fmt, ...) {
     if (c) {
@@ -277,39 +344,68 @@ double adaptive_threshold(sgs_ctx *c) {
     return sqrt(c->model_error_sse2 / c->num_samples);
 }
 
+// The Gauss-Newton loop (F/Registration.cpp:159-173) stays on the device: the host only keeps a small
+// window of iterations enqueued ahead of the last one it has seen finish, by polling a host-mapped
+// mailbox the solve kernel writes (no copy, no stream sync inside the loop).  Iterations enqueued past
+// convergence exit on the device-side done flag.
+constexpr int kIcpWindow = 3;
+constexpr int kIcpMaxIter = 500;  // MAX_NUM_ITERATIONS_ (F/Registration.cpp:115)
+
+int enqueue_icp_iteration(sgs_ctx *c, CloudView src, const int32_t *n_ptr) {
+    if (c->profiling) {
+        if (c->icp_events_used == c->icp_events.size()) {
+            hipEvent_t a, b;
+            SGS_HIP(c, hipEventCreate(&a));
+            SGS_HIP(c, hipEventCreate(&b));
+            c->icp_events.emplace_back(a, b);
+        }
+        auto &ev = c->icp_events[c->icp_events_used++];
+        SGS_HIP(c, hipEventRecord(ev.first, c->stream));
+        launch_icp_iteration(c->stream, c->map.v, src, n_ptr, c->st, c->partials, false, nullptr);
+        SGS_HIP(c, hipEventRecord(ev.second, c->stream));
+        launch_icp_iteration_solve_only(c->stream, c->st, c->partials, c->mailbox_dev);
+    } else {
+        launch_icp_iteration(c->stream, c->map.v, src, n_ptr, c->st, c->partials, true, c->mailbox_dev);
+    }
+    return SGS_OK;
+}
+
 int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const Rigid &guess, double max_corr, double kernel_th,
             int *iters_out) {
-    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, 500, 0);
+    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, 0);
     *iters_out = 0;
     if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
-    int launched = 0;
-    int chunk = std::min(32, std::max(4, c->prev_iters + 2));
+    volatile int32_t *mb = c->mailbox;
+    mb[0] = 0;
+    mb[1] = 0;
+    __sync_synchronize();
+    int launched = 0, r;
     while (true) {
-        for (int k = 0; k < chunk; ++k) {
-            if (c->profiling) {
-                if (c->icp_events_used == c->icp_events.size()) {
-                    hipEvent_t a, b;
-                    SGS_HIP(c, hipEventCreate(&a));
-                    SGS_HIP(c, hipEventCreate(&b));
-                    c->icp_events.emplace_back(a, b);
+        const int done = __atomic_load_n(&mb[1], __ATOMIC_ACQUIRE);
+        const int completed = __atomic_load_n(&mb[0], __ATOMIC_ACQUIRE);
+        if (done || completed >= kIcpMaxIter) break;
+        while (launched < completed + kIcpWindow && launched < kIcpMaxIter) {
+            if ((r = enqueue_icp_iteration(c, src, n_ptr))) return r;
+            ++launched;
+        }
+        // wait for the next iteration to retire
+        long spins = 0;
+        while (__atomic_load_n(&mb[0], __ATOMIC_ACQUIRE) == completed && !__atomic_load_n(&mb[1], __ATOMIC_ACQUIRE)) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) {  // stream drained: re-read once, the kernels must have written
+                    if (__atomic_load_n(&mb[0], __ATOMIC_ACQUIRE) == completed && !__atomic_load_n(&mb[1], __ATOMIC_ACQUIRE))
+                        return fail(c, SGS_EHIP, "ICP mailbox did not advance although the stream is idle");
+                } else if (q != hipErrorNotReady) {
+                    return fail(c, SGS_EHIP, "ICP loop: %s", hipGetErrorString(q));
                 }
-                auto &ev = c->icp_events[c->icp_events_used++];
-                SGS_HIP(c, hipEventRecord(ev.first, c->stream));
-                launch_icp_iteration(c->stream, c->map.v, src, n_ptr, c->st, c->partials, false);
-                SGS_HIP(c, hipEventRecord(ev.second, c->stream));
-                launch_icp_iteration_solve_only(c->stream, c->st, c->partials);
-            } else {
-                launch_icp_iteration(c->stream, c->map.v, src, n_ptr, c->st, c->partials, true);
             }
         }
-        launched += chunk;
-        SGS_HIP(c, hipMemcpyAsync(c->st_host, c->st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
-        SGS_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->st_host->icp_done || launched >= 500) break;
-        chunk = 8;
     }
-    *iters_out = c->st_host->icp_iter;
-    c->prev_iters = c->st_host->icp_iter;
+    const int iters = __atomic_load_n(&mb[0], __ATOMIC_ACQUIRE);
+    *iters_out = iters;
+    c->prev_iters = iters;
     return SGS_OK;
 }
 
@@ -328,6 +424,7 @@ void drain_icp_events(sgs_ctx *c, int iterations_run) {
 int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const int32_t *d_label, int n,
                      const double *d_ts, int is_kitti, sgs_scan_result *res) {
     if (n < 0 || n > c->N) return fail(c, SGS_ECAPACITY, "scan of %d points exceeds max_points=%d", n, c->N);
+    const double t_call0 = now_ms();
     hipStream_t s = c->stream;
     const sgs_config &cfg = c->cfg;
     if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[0], s);
@@ -352,6 +449,29 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     jobs[0] = make_job(c, 0, c->cropped, &c->st->n_in, cfg.voxel_size_cluster, c->cluster, &c->st->n_c, nullptr);
     jobs[1] = make_job(c, 1, c->cropped, &c->st->n_in, cfg.voxel_size * 0.5, c->ds, &c->st->n_d, nullptr);
     launch_downsample(s, jobs, 2, n, c->st);
+    // ---- instance clustering (P/SemGraphSLAM.cpp:41-46) on the 0.2 m cloud: second stream, overlaps the ICP
+    int rg = SGS_OK;
+    if (cfg.enable_graph) {
+        SGS_HIP(c, hipEventRecord(c->ev_ds, s));
+        SGS_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_ds, 0));
+        if (c->profiling) hipEventRecord(c->ev_g0, c->stream2);
+        rg = graph_cluster_enqueue(c->stream2, c->gs, c->cluster, &c->st->n_c, n, cfg, &c->err);
+        if (rg) return rg;
+        c->gworker.submit([c] {
+            const double t_g0 = now_ms();
+            int nb = 0;
+            const int r = graph_finish_scan(c->stream2, c->gs, c->cluster, &c->st->n_c, c->cfg, &c->last_boxes, &nb, &c->gerr);
+            c->job_n_boxes = nb;
+            if (c->profiling) hipEventRecord(c->ev_g1, c->stream2);
+            c->stats.stage_ms[5] += now_ms() - t_g0;  // host wall time of cluster read-back + graph (helper thread)
+            return r;
+        });
+    }
+    struct JobGuard {  // never leave the helper running past this call
+        sgs_ctx *c;
+        bool armed;
+        ~JobGuard() { if (armed) c->gworker.wait(); }
+    } guard{c, cfg.enable_graph != 0};
     DsJob j3 = make_job(c, 0, c->ds, &c->st->n_d, cfg.voxel_size * 1.5, c->src, &c->st->n_s, nullptr);
     launch_downsample(s, &j3, 1, n, c->st);
     if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[2], s);
@@ -364,7 +484,9 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     const Rigid guess = compose(last_pose, prediction);
     // ---- registration (P/SemGraphSLAM.cpp:72-76)
     int iters = 0;
+    const double t_icp0 = now_ms();
     int r = run_icp(c, c->src, &c->st->n_s, guess, 3.0 * sigma, sigma / 3.0, &iters);
+    c->stats.stage_ms[7] += now_ms() - t_icp0;  // host wall time of the ICP loop
     if (r) return r;
     if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[3], s);
     // ---- local map update with the new pose, still on the device (P/SemGraphSLAM.cpp:113)
@@ -373,15 +495,19 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     launch_map_add(s, c->map.v, c->ds, &c->st->n_d, n, &c->st->T_total, c->map_slot_of, c->map_next, c->world, c->st);
     launch_map_sweep(s, c->map.v, &c->st->T_total, nullptr, cfg.max_range, 1, c->map_blockstat, c->st);
     if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[4], s);
-    // ---- instance clustering + graph (P/SemGraphSLAM.cpp:41-51) on the 0.2 m cloud
+    // ---- collect the clusters, emit boxes in the reference's order, build the graph (P/SemGraphSLAM.cpp:44-51)
     int n_boxes = 0;
-    if (cfg.enable_graph) {
-        r = graph_process_scan(c->stream, c->gs, c->cluster, &c->st->n_c, n, cfg, &c->last_boxes, &n_boxes, &c->err);
-        if (r) return r;
-    }
-    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[5], s);
     r = sync_state(c);
     if (r) return r;
+    if (cfg.enable_graph) {
+        guard.armed = false;
+        r = c->gworker.wait();
+        if (r) {
+            c->err = c->gerr;
+            return r;
+        }
+        n_boxes = c->job_n_boxes;
+    }
     r = check_err_flags(c);
     if (r) return r;
     const DevState &h = *c->st_host;
@@ -391,16 +517,22 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     c->poses.push_back(new_pose);
     c->last_n[0] = n; c->last_n[1] = h.n_in; c->last_n[2] = h.n_c; c->last_n[3] = h.n_d; c->last_n[4] = h.n_s;
     c->stats.scans++;
+    c->stats.stage_ms[6] += now_ms() - t_call0;  // host wall time of the whole call
     c->stats.icp_queries_total += (int64_t)h.n_s * iters;
     c->stats.icp_candidates_total += h.icp_cand;
     c->stats.icp_probes_total += h.icp_probe;
     if (c->profiling) {
         drain_icp_events(c, iters);
         if (c->stage_ev_ok)
-            for (int k = 0; k < 5; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, c->stage_ev[k], c->stage_ev[k + 1]) == hipSuccess) c->stats.stage_ms[k] += ms;
             }
+        if (cfg.enable_graph) {
+            float ms = 0.f;
+            hipStreamSynchronize(c->stream2);
+            if (hipEventElapsedTime(&ms, c->ev_g0, c->ev_g1) == hipSuccess) c->stats.stage_ms[4] += ms;
+        }
     }
     if (res) {
         const uint32_t sz = res->size ? std::min<uint32_t>(res->size, sizeof(sgs_scan_result)) : sizeof(sgs_scan_result);
@@ -498,6 +630,13 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
         return code;
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(SGS_EHIP);
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return bail(SGS_EHIP);
+    if (hipEventCreateWithFlags(&c->ev_ds, hipEventDisableTiming) != hipSuccess || hipEventCreate(&c->ev_g0) != hipSuccess ||
+        hipEventCreate(&c->ev_g1) != hipSuccess)
+        return bail(SGS_EHIP);
+    if (hipHostMalloc((void **)&c->mailbox, 64, hipHostMallocMapped) != hipSuccess) return bail(SGS_ENOMEM);
+    if (hipHostGetDevicePointer((void **)&c->mailbox_dev, c->mailbox, 0) != hipSuccess) return bail(SGS_EHIP);
+    memset(c->mailbox, 0, 64);
     if ((r = dev_alloc(c, &c->in_f32, N * 4))) return bail(r);
     if ((r = dev_alloc(c, &c->in_f64, N * 3))) return bail(r);
     if ((r = dev_alloc(c, &c->in_label, N))) return bail(r);
@@ -530,6 +669,7 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     if (hipHostMalloc((void **)&c->st_host, sizeof(DevState), hipHostMallocDefault) != hipSuccess) return bail(SGS_ENOMEM);
     if ((r = alloc_map(c, &c->map, cfg.map_capacity_log2))) return bail(r);
     if ((r = graph_scratch_alloc(c->gs, c->N))) return bail(fail(c, r, "graph scratch allocation failed"));
+    c->gworker.start(device);
     if (hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream) != hipSuccess) return bail(SGS_EHIP);
     launch_map_clear(c->stream, c->map.v, c->st);
     for (int k = 0; k < 8; ++k)
@@ -543,7 +683,14 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
 void sgs_destroy(sgs_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    c->gworker.stop();
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream2) hipStreamSynchronize(c->stream2);
+    if (c->ev_ds) hipEventDestroy(c->ev_ds);
+    if (c->ev_g0) hipEventDestroy(c->ev_g0);
+    if (c->ev_g1) hipEventDestroy(c->ev_g1);
+    if (c->mailbox) hipHostFree(c->mailbox);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     for (void *p : c->allocs) hipFree(p);
     free_map(&c->map);
     graph_scratch_free(c->gs);
@@ -819,7 +966,7 @@ int sgs_build_linear_system(sgs_ctx *c, const double *xyzl_world, int n, double 
     int r;
     if ((r = upload_xyzl(c, xyzl_world, n, c->aux))) return r;  // aux_n[0] = n
     launch_icp_init(c->stream, c->st, rigid_identity(), max_distance, kernel, 1, 1);
-    launch_icp_iteration(c->stream, c->map.v, c->aux, &c->aux_n[0], c->st, c->partials, false);
+    launch_icp_iteration(c->stream, c->map.v, c->aux, &c->aux_n[0], c->st, c->partials, false, nullptr);
     launch_linear_system_finish(c->stream, c->st, c->partials, c->out28);
     double h[28];
     SGS_HIP(c, hipMemcpyAsync(h, c->out28, sizeof(h), hipMemcpyDeviceToHost, c->stream));

@@ -57,7 +57,7 @@ struct MapView {
 };
 
 constexpr int kIcpSums = 20;  // 16 moment sums + n_corr + candidates + probes + spare
-constexpr int kIcpBlocks = 512;
+constexpr int kIcpBlocks = 256;
 constexpr int kIcpThreads = 512;
 
 struct DevState {
@@ -113,8 +113,8 @@ void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max
 // one Gauss-Newton iteration = fused correspondence search + linear-system reduction, then solve.
 // corr_* (optional) receive per-query results for sgs_map_get_correspondences.
 void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, const int32_t *n_ptr, DevState *st,
-                          double *partials, bool solve);
-void launch_icp_iteration_solve_only(hipStream_t s, DevState *st, double *partials);
+                          double *partials, bool solve, int32_t *mailbox /*host-mapped, nullable*/);
+void launch_icp_iteration_solve_only(hipStream_t s, DevState *st, double *partials, int32_t *mailbox);
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
                             int32_t *found);
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out27_dev);

@@ -58,6 +58,9 @@ struct GraphScratch {
     // host staging
     ClassParams params_host[kNumFgClasses];
     std::vector<float> last_desc;     // node descriptors of the last processed scan
+    std::vector<ClusterStat> stat_host;
+    char *pinned = nullptr;           // 1 KiB host-pinned landing zone for counts + class parameters
+    int enqueued_upper = 0;
 };
 
 constexpr int kMaxNodes = 1024;
@@ -71,9 +74,13 @@ void graph_scratch_free(GraphScratch &g);
 int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper, const sgs_config &cfg,
                   std::vector<double> *boxes, int *n_boxes, int32_t *point_cluster_host, int *n_fg, int *n_bg,
                   std::string *err);
-// cluster + graph for the pipeline (graph outputs are kept in g for later retrieval)
-int graph_process_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper,
-                       const sgs_config &cfg, std::vector<double> *boxes, int *n_boxes, std::string *err);
+// pipeline form: enqueue (kernels only, no host sync) early, finish (+ graph) after the ICP loop
+int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper,
+                          const sgs_config &cfg, std::string *err);
+int graph_cluster_finish(hipStream_t s, GraphScratch &g, const int32_t *n_ptr, std::vector<double> *boxes, int *n_boxes,
+                         int32_t *point_cluster_host, int *n_fg, int *n_bg, std::string *err);
+int graph_finish_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, const sgs_config &cfg,
+                      std::vector<double> *boxes, int *n_boxes, std::string *err);
 int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
                 double subgraph_edge_th, float *desc, double *edge_matrix, double *eigenvalues, int32_t *edges,
                 double *edge_value, double *edge_weights, int edge_cap, int *n_edges, int32_t *tri_counts,

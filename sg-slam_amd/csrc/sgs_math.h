@@ -177,6 +177,129 @@ SGS_HD void solve6(double A[6][6], const double *b, double *x) {
     for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
+// Same algorithm as solve6 with every index a compile-time constant (the pivot is dispatched through
+// if-chains over constant cases), so the 6x6 system lives in registers on the GPU instead of in
+// scratch memory: a runtime-indexed private array costs a memory round trip per access.
+namespace detail {
+template <int K, int P>
+SGS_HD void sym_swap(double (&A)[6][6]) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) { const double t = A[K][j]; A[K][j] = A[P][j]; A[P][j] = t; }
+#pragma unroll
+    for (int i = P + 1; i < 6; ++i) { const double t = A[i][K]; A[i][K] = A[i][P]; A[i][P] = t; }
+    { const double t = A[K][K]; A[K][K] = A[P][P]; A[P][P] = t; }
+#pragma unroll
+    for (int i = K + 1; i < P; ++i) { const double t = A[i][K]; A[i][K] = A[P][i]; A[P][i] = t; }
+}
+template <int K>
+SGS_HD void pivot_swap(double (&A)[6][6], int p) {
+    if constexpr (K + 1 < 6) { if (p == K + 1) sym_swap<K, K + 1>(A); }
+    if constexpr (K + 2 < 6) { if (p == K + 2) sym_swap<K, K + 2>(A); }
+    if constexpr (K + 3 < 6) { if (p == K + 3) sym_swap<K, K + 3>(A); }
+    if constexpr (K + 4 < 6) { if (p == K + 4) sym_swap<K, K + 4>(A); }
+    if constexpr (K + 5 < 6) { if (p == K + 5) sym_swap<K, K + 5>(A); }
+}
+template <int K>
+SGS_HD void vec_swap(double (&y)[6], int p) {
+    if constexpr (K + 1 < 6) { if (p == K + 1) { const double t = y[K]; y[K] = y[K + 1]; y[K + 1] = t; } }
+    if constexpr (K + 2 < 6) { if (p == K + 2) { const double t = y[K]; y[K] = y[K + 2]; y[K + 2] = t; } }
+    if constexpr (K + 3 < 6) { if (p == K + 3) { const double t = y[K]; y[K] = y[K + 3]; y[K + 3] = t; } }
+    if constexpr (K + 4 < 6) { if (p == K + 4) { const double t = y[K]; y[K] = y[K + 4]; y[K + 4] = t; } }
+    if constexpr (K + 5 < 6) { if (p == K + 5) { const double t = y[K]; y[K] = y[K + 5]; y[K + 5] = t; } }
+}
+template <int K>
+SGS_HD void ldlt_column(double (&A)[6][6], int (&tr)[6], bool &zero) {
+    tr[K] = K;
+    if (zero) return;
+    int p = K;
+    double best = fabs(A[K][K]);
+#pragma unroll
+    for (int i = K + 1; i < 6; ++i) {
+        const double v = fabs(A[i][i]);
+        if (v > best) { best = v; p = i; }
+    }
+    tr[K] = p;
+    pivot_swap<K>(A, p);
+    double tmp[6];
+#pragma unroll
+    for (int j = 0; j < K; ++j) tmp[j] = A[j][j] * A[K][j];
+    if constexpr (K > 0) {
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) s += A[K][j] * tmp[j];
+        A[K][K] -= s;
+#pragma unroll
+        for (int i = K + 1; i < 6; ++i) {
+            double s2 = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) s2 += A[i][j] * tmp[j];
+            A[i][K] -= s2;
+        }
+    }
+    const double akk = A[K][K];
+    if (K == 0 && !(fabs(akk) > 0.0)) { zero = true; return; }
+    if (fabs(akk) > 0.0) {
+#pragma unroll
+        for (int i = K + 1; i < 6; ++i) A[i][K] /= akk;
+    }
+}
+}  // namespace detail
+
+SGS_HD void solve6_static(double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
+    int tr[6];
+    bool zero = false;
+    detail::ldlt_column<0>(A, tr, zero);
+    detail::ldlt_column<1>(A, tr, zero);
+    detail::ldlt_column<2>(A, tr, zero);
+    detail::ldlt_column<3>(A, tr, zero);
+    detail::ldlt_column<4>(A, tr, zero);
+    detail::ldlt_column<5>(A, tr, zero);
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = b[i];
+    detail::vec_swap<0>(y, tr[0]); detail::vec_swap<1>(y, tr[1]); detail::vec_swap<2>(y, tr[2]);
+    detail::vec_swap<3>(y, tr[3]); detail::vec_swap<4>(y, tr[4]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) y[i] -= A[i][j] * y[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = (fabs(A[i][i]) > 2.2250738585072014e-308) ? y[i] / A[i][i] : 0.0;
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) y[i] -= A[j][i] * y[j];
+    detail::vec_swap<4>(y, tr[4]); detail::vec_swap<3>(y, tr[3]); detail::vec_swap<2>(y, tr[2]);
+    detail::vec_swap<1>(y, tr[1]); detail::vec_swap<0>(y, tr[0]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = y[i];
+}
+
+// exp for the small Gauss-Newton updates on the device: one sincos of theta/2, the full-angle terms
+// from double-angle identities (differs from rigid_exp by rounding only)
+SGS_HD Rigid rigid_exp_small(const double *a) {
+    const D3 v{a[0], a[1], a[2]}, w{a[3], a[4], a[5]};
+    const double th2 = sq3(w);
+    if (th2 < kTiny * kTiny) return rigid_exp(a);
+    const double theta = sqrt(th2);
+    const double h = 0.5 * theta;
+    double sh, ch;
+    sincos(h, &sh, &ch);
+    const double im = sh / theta;
+    Rigid T;
+    T.qw = ch; T.qx = im * w.x; T.qy = im * w.y; T.qz = im * w.z;
+    const double n = sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
+    T.qw /= n; T.qx /= n; T.qy /= n; T.qz /= n;
+    const double one_minus_cos = 2.0 * sh * sh;     // 1 - cos(theta)
+    const double sin_theta = 2.0 * sh * ch;
+    const double c1 = one_minus_cos / th2;
+    const double c2 = (theta - sin_theta) / (th2 * theta);
+    const D3 wv = crs(w, v);
+    const D3 wwv = crs(w, wv);
+    T.t = add(v, add(scale(c1, wv), scale(c2, wwv)));
+    return T;
+}
+
 // ---- voxel keys ----
 struct K3 {
     int32_t x, y, z;
