@@ -1,0 +1,330 @@
+// Header-only C++ facade: the reference's own names and signatures (namespace graph_slam) on top of
+// the C ABI in include/sgs.h.  A maintainer of nubot-nudt/SG-SLAM swaps these declarations in for
+//   semgraph_slam/frontend/Preprocessing.hpp:38-52, Deskew.hpp:33-36, VoxelHashMap.hpp:37-83,
+//   Registration.hpp:62-66, SemanticCluster.hpp:81-87, SemGraph.hpp:18
+// and links libsgs_hip.so; SemGraphSLAM::mainProcess (pipeline/SemGraphSLAM.cpp:16-121) compiles unchanged.
+//
+// With Eigen + Sophus available the facade uses them (SGS_FACADE_WITH_EIGEN, auto-detected).  Without
+// (this build container has neither) it is instantiated on the small POD types below so that it is
+// still compiled and exercised by tests/test_facade.cpp.
+//
+// Value semantics like the reference: inputs by const&, fresh vectors returned by value.  Errors: the
+// reference has no error channel (silent degenerate cases, F/Registration.cpp:152); the facade logs to
+// stderr and returns empty/identity results, it never throws.
+#pragma once
+#include <array>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "sgs.h"
+
+#if !defined(SGS_FACADE_WITH_EIGEN) && defined(__has_include)
+#if __has_include(<Eigen/Core>) && __has_include(<sophus/se3.hpp>)
+#define SGS_FACADE_WITH_EIGEN 1
+#endif
+#endif
+
+#if SGS_FACADE_WITH_EIGEN
+#include <Eigen/Core>
+#include <sophus/se3.hpp>
+#endif
+
+namespace graph_slam {
+
+#if SGS_FACADE_WITH_EIGEN
+using Vec3 = Eigen::Vector3d;
+using Vec4 = Eigen::Vector4d;
+using Pose = Sophus::SE3d;
+inline void pose_to7(const Pose &T, double *p) {
+    const auto q = T.unit_quaternion();
+    p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); p[3] = q.w();
+    p[4] = T.translation().x(); p[5] = T.translation().y(); p[6] = T.translation().z();
+}
+inline Pose pose_from7(const double *p) {
+    return Pose(Eigen::Quaterniond(p[3], p[0], p[1], p[2]), Eigen::Vector3d(p[4], p[5], p[6]));
+}
+#else
+struct Vec3 {
+    double v[3];
+    double &operator[](int i) { return v[i]; }
+    double operator[](int i) const { return v[i]; }
+    const double *data() const { return v; }
+    double *data() { return v; }
+};
+struct Vec4 {
+    double v[4];
+    double &operator[](int i) { return v[i]; }
+    double operator[](int i) const { return v[i]; }
+    const double *data() const { return v; }
+    double *data() { return v; }
+};
+struct Pose {  // [qx,qy,qz,qw,tx,ty,tz]
+    double p[7] = {0, 0, 0, 1, 0, 0, 0};
+};
+inline void pose_to7(const Pose &T, double *p) { for (int i = 0; i < 7; ++i) p[i] = T.p[i]; }
+inline Pose pose_from7(const double *p) { Pose T; for (int i = 0; i < 7; ++i) T.p[i] = p[i]; return T; }
+#endif
+static_assert(sizeof(Vec3) == 3 * sizeof(double) && sizeof(Vec4) == 4 * sizeof(double), "dense xyz / xyzl layout expected");
+
+// core/Coreutils.h:34-56
+typedef std::pair<std::vector<Vec3>, std::vector<int>> V3d_i;
+typedef std::vector<Vec4> V4d;
+typedef std::vector<Vec3> V3d;
+struct Bbox {
+    Vec3 center;
+    Vec3 dimension;
+    double theta = 0.0;
+    int label = -1;
+    double score = 0.0;
+    int points_num = 0;
+};
+// core/Coreutils.h:59-78 (dense matrices flattened row-major instead of Eigen::MatrixXd)
+struct Graph {
+    std::vector<int> node_labels, points_num;
+    std::vector<Vec3> node_centers, node_dimensions;
+    std::vector<std::vector<Vec3>> node_sub_triangles;
+    std::vector<std::vector<float>> node_desc;
+    std::vector<std::pair<int, int>> edges;
+    std::vector<double> edge_value, edge_weights;
+    std::vector<double> edge_matrix;  // N*N
+    V3d_i back_points, front_points;
+    int vehicle_num = 0, trunk_num = 0, pole_like_num = 0;
+};
+
+// One device context per thread of use (the reference's VoxelHashMap is not thread safe either).
+class HipContext {
+public:
+    static HipContext &instance() {
+        static HipContext c;
+        return c;
+    }
+    sgs_ctx *get(const sgs_config *cfg = nullptr) {
+        if (!ctx_) {
+            sgs_config c;
+            if (cfg) c = *cfg; else sgs_preset("kitti", &c);
+            if (sgs_create(&c, 0, &ctx_) != SGS_OK) {
+                std::fprintf(stderr, "[graph_slam_hip] sgs_create failed: no HIP device or out of memory\n");
+                ctx_ = nullptr;
+            }
+        }
+        return ctx_;
+    }
+    ~HipContext() { if (ctx_) sgs_destroy(ctx_); }
+private:
+    sgs_ctx *ctx_ = nullptr;
+};
+inline bool ok(sgs_ctx *c, int r, const char *what) {
+    if (r == SGS_OK) return true;
+    std::fprintf(stderr, "[graph_slam_hip] %s: %s\n", what, c ? sgs_last_error(c) : "no context");
+    return false;
+}
+
+// ---- Preprocessing.hpp ----
+inline V3d_i PreprocessSemantic(const std::vector<Vec3> &frame, const std::vector<int> &label, double max_range,
+                                double min_range) {
+    V3d_i out;
+    sgs_ctx *c = HipContext::instance().get();
+    if (!c || frame.empty()) return out;
+    const int n = (int)frame.size();
+    out.first.resize(frame.size());
+    out.second.resize(frame.size());
+    int m = 0;
+    if (!ok(c, sgs_preprocess(c, frame[0].data(), label.data(), n, max_range, min_range, out.first[0].data(),
+                              out.second.data(), n, &m), "PreprocessSemantic"))
+        m = 0;
+    out.first.resize((size_t)m);
+    out.second.resize((size_t)m);
+    return out;
+}
+inline std::vector<Vec3> CorrectKITTIScan(const std::vector<Vec3> &frame) {
+    std::vector<Vec3> out(frame.size());
+    sgs_ctx *c = HipContext::instance().get();
+    if (c && !frame.empty()) ok(c, sgs_correct_kitti(c, frame[0].data(), (int)frame.size(), out[0].data()), "CorrectKITTIScan");
+    return out;
+}
+inline V3d_i VoxelDownsampleSemantic(const V3d_i &frame, double voxel_size) {
+    V3d_i out;
+    sgs_ctx *c = HipContext::instance().get();
+    if (!c || frame.first.empty()) return out;
+    const int n = (int)frame.first.size();
+    out.first.resize((size_t)n);
+    out.second.resize((size_t)n);
+    int m = 0;
+    if (!ok(c, sgs_voxel_downsample(c, frame.first[0].data(), frame.second.data(), n, voxel_size, out.first[0].data(),
+                                    out.second.data(), nullptr, n, &m), "VoxelDownsampleSemantic"))
+        m = 0;
+    out.first.resize((size_t)m);
+    out.second.resize((size_t)m);
+    return out;
+}
+// ---- Deskew.hpp ----
+inline std::vector<Vec3> DeSkewScan(const std::vector<Vec3> &frame, const std::vector<double> &timestamps,
+                                    const Pose &start_pose, const Pose &finish_pose) {
+    std::vector<Vec3> out(frame.size());
+    sgs_ctx *c = HipContext::instance().get();
+    double a[7], b[7];
+    pose_to7(start_pose, a);
+    pose_to7(finish_pose, b);
+    if (c && !frame.empty())
+        ok(c, sgs_deskew(c, frame[0].data(), timestamps.data(), (int)frame.size(), a, b, out[0].data()), "DeSkewScan");
+    return out;
+}
+
+// ---- VoxelHashMap.hpp:37-83 ----
+struct VoxelHashMap {
+    using Vector4dVectorTuple = std::tuple<V4d, V4d>;
+    explicit VoxelHashMap(double voxel_size, double max_distance, int max_points_per_voxel)
+        : voxel_size_(voxel_size), max_distance_(max_distance), max_points_per_voxel_(max_points_per_voxel) {
+        sgs_config cfg;
+        sgs_preset("kitti", &cfg);
+        cfg.voxel_size = voxel_size;
+        cfg.max_range = max_distance;
+        cfg.max_points_per_voxel = max_points_per_voxel;
+        sgs_ctx *c = nullptr;
+        if (sgs_create(&cfg, 0, &c) == SGS_OK) ctx_.reset(c, sgs_destroy);
+        else std::fprintf(stderr, "[graph_slam_hip] VoxelHashMap: sgs_create failed\n");
+    }
+    Vector4dVectorTuple GetCorrespondences(const V4d &points, double max_correspondance_distance) const {
+        V4d src(points.size()), tgt(points.size());
+        int m = 0;
+        if (ctx_ && !points.empty())
+            ok(ctx_.get(), sgs_map_get_correspondences(ctx_.get(), points[0].data(), (int)points.size(), max_correspondance_distance,
+                                                       src[0].data(), tgt[0].data(), nullptr, (int)points.size(), &m), "GetCorrespondences");
+        src.resize((size_t)m);
+        tgt.resize((size_t)m);
+        return std::make_tuple(src, tgt);
+    }
+    inline void Clear() { if (ctx_) sgs_map_clear(ctx_.get()); }
+    inline bool Empty() const {
+        int e = 1;
+        if (ctx_) sgs_map_empty(ctx_.get(), &e);
+        return e != 0;
+    }
+    void Update(const V4d &points, const Vec3 &origin) {
+        AddPoints(points);
+        RemovePointsFarFromLocation(origin);
+    }
+    void Update(const V4d &points, const Pose &pose) {
+        double p[7];
+        pose_to7(pose, p);
+        if (ctx_) ok(ctx_.get(), sgs_map_update(ctx_.get(), points.empty() ? nullptr : points[0].data(), (int)points.size(), p), "Update");
+    }
+    void AddPoints(const V4d &points) {
+        if (ctx_ && !points.empty()) ok(ctx_.get(), sgs_map_add_points(ctx_.get(), points[0].data(), (int)points.size()), "AddPoints");
+    }
+    void RemovePointsFarFromLocation(const Vec3 &origin) {
+        if (ctx_) ok(ctx_.get(), sgs_map_prune(ctx_.get(), origin.data()), "RemovePointsFarFromLocation");
+    }
+    std::vector<Vec4> Pointcloud() const {
+        std::vector<Vec4> out;
+        if (!ctx_) return out;
+        int v = 0, np = 0;
+        sgs_map_size(ctx_.get(), &v, &np);
+        out.resize((size_t)np);
+        int n = 0;
+        if (np) ok(ctx_.get(), sgs_map_pointcloud(ctx_.get(), out[0].data(), np, &n), "Pointcloud");
+        out.resize((size_t)n);
+        return out;
+    }
+    sgs_ctx *ctx() const { return ctx_.get(); }
+    double voxel_size_;
+    double max_distance_;
+    int max_points_per_voxel_;
+private:
+    std::shared_ptr<sgs_ctx> ctx_;
+};
+
+// ---- Registration.hpp:62-66 ----
+inline Pose RegisterFrameSemantic(const std::vector<Vec4> &frame, const VoxelHashMap &voxel_map, const Pose &initial_guess,
+                                  double max_correspondence_distance, double kernel) {
+    double g[7], out[7];
+    pose_to7(initial_guess, g);
+    int it = 0;
+    if (!voxel_map.ctx() ||
+        !ok(voxel_map.ctx(), sgs_register_frame(voxel_map.ctx(), frame.empty() ? nullptr : frame[0].data(), (int)frame.size(), g,
+                                                max_correspondence_distance, kernel, out, &it), "RegisterFrameSemantic"))
+        return initial_guess;
+    return pose_from7(out);
+}
+
+// ---- SemanticCluster.hpp:81-87 ----
+inline std::vector<Bbox> ClusterPoints(const std::vector<Vec3> &frame, const std::vector<int> &frame_label, V3d_i &background_points,
+                                       V3d_i &ClusterSemPoints, double delta_azimuth, double delta_range, double delta_polar) {
+    std::vector<Bbox> out;
+    // foreground / background splits are plain order-preserving label filters (SemanticCluster.cpp:222-244)
+    for (size_t i = 0; i < frame.size(); ++i) {
+        const int L = frame_label[i];
+        if (L == 1 || L == 4 || L == 5 || L == 16 || L == 18) { ClusterSemPoints.first.push_back(frame[i]); ClusterSemPoints.second.push_back(L); }
+        if (L == 14 || L == 15 || L == 9 || L == 13) { background_points.first.push_back(frame[i]); background_points.second.push_back(L); }
+    }
+    sgs_ctx *c = HipContext::instance().get();
+    if (!c || frame.empty()) return out;
+    std::vector<double> boxes(8 * 1024);
+    int nb = 0, nfg = 0, nbg = 0;
+    if (!ok(c, sgs_cluster_points(c, frame[0].data(), frame_label.data(), (int)frame.size(), delta_azimuth, delta_range, delta_polar,
+                                  boxes.data(), 1024, &nb, nullptr, &nfg, &nbg), "ClusterPoints"))
+        return out;
+    out.resize((size_t)nb);
+    for (int i = 0; i < nb; ++i) {
+        const double *b = &boxes[8 * (size_t)i];
+        for (int k = 0; k < 3; ++k) { out[(size_t)i].center[k] = b[k]; out[(size_t)i].dimension[k] = b[3 + k]; }
+        out[(size_t)i].label = (int)b[6];
+        out[(size_t)i].points_num = (int)b[7];
+    }
+    return out;
+}
+
+// ---- SemGraph.hpp:18 ----
+inline Graph BuildGraph(const std::vector<Bbox> &cluster_boxes, double edge_dis_th, int subinterval, int graph_node_dimension,
+                        double subgraph_edge_th) {
+    Graph g;
+    const int nb = (int)cluster_boxes.size();
+    std::vector<double> boxes(8 * (size_t)nb);
+    for (int i = 0; i < nb; ++i) {
+        double *b = &boxes[8 * (size_t)i];
+        for (int k = 0; k < 3; ++k) { b[k] = cluster_boxes[(size_t)i].center[k]; b[3 + k] = cluster_boxes[(size_t)i].dimension[k]; }
+        b[6] = cluster_boxes[(size_t)i].label;
+        b[7] = cluster_boxes[(size_t)i].points_num;
+        g.node_labels.push_back(cluster_boxes[(size_t)i].label);
+        g.node_centers.push_back(cluster_boxes[(size_t)i].center);
+        g.node_dimensions.push_back(cluster_boxes[(size_t)i].dimension);
+        g.points_num.push_back(cluster_boxes[(size_t)i].points_num);
+    }
+    sgs_ctx *c = HipContext::instance().get();
+    if (!c || nb == 0) return g;
+    const int D = 3 * subinterval + graph_node_dimension;
+    std::vector<float> desc((size_t)nb * D);
+    g.edge_matrix.assign((size_t)nb * nb, 0.0);
+    const int ecap = nb * nb, tcap = nb * nb * nb;
+    std::vector<int32_t> edges(2 * (size_t)ecap), tri_counts((size_t)nb);
+    std::vector<double> ev((size_t)ecap), ew((size_t)ecap), tri(3 * (size_t)tcap);
+    int ne = 0, nt = 0;
+    int32_t cc[3] = {0, 0, 0};
+    if (!ok(c, sgs_build_graph(c, boxes.data(), nb, edge_dis_th, subinterval, graph_node_dimension, subgraph_edge_th, desc.data(),
+                               g.edge_matrix.data(), nullptr, edges.data(), ev.data(), ew.data(), ecap, &ne, tri_counts.data(),
+                               tri.data(), tcap, &nt, cc), "BuildGraph"))
+        return g;
+    g.vehicle_num = cc[0]; g.trunk_num = cc[1]; g.pole_like_num = cc[2];
+    for (int i = 0; i < nb; ++i) g.node_desc.emplace_back(desc.begin() + (size_t)i * D, desc.begin() + (size_t)(i + 1) * D);
+    for (int i = 0; i < ne; ++i) {
+        g.edges.emplace_back(edges[2 * (size_t)i], edges[2 * (size_t)i + 1]);
+        g.edge_value.push_back(ev[(size_t)i]);
+        g.edge_weights.push_back(ew[(size_t)i]);
+    }
+    size_t t = 0;
+    for (int i = 0; i < nb; ++i) {
+        g.node_sub_triangles.emplace_back();
+        for (int k = 0; k < tri_counts[(size_t)i]; ++k, ++t) {
+            Vec3 v;
+            v[0] = tri[3 * t]; v[1] = tri[3 * t + 1]; v[2] = tri[3 * t + 2];
+            g.node_sub_triangles.back().push_back(v);
+        }
+    }
+    return g;
+}
+
+}  // namespace graph_slam

@@ -1,0 +1,43 @@
+// Compiles the header-only facade (reference names/signatures) against the C ABI and, when a GPU is
+// present, runs a tiny registration through it.  Built and run by tests/test_facade.py.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "graph_slam_hip.hpp"
+
+using namespace graph_slam;
+
+int main() {
+    std::mt19937 rng(5);
+    std::uniform_real_distribution<double> u(0.0, 1.0);
+    V4d scene(6000);
+    for (auto &p : scene) { p[0] = 40 * u(rng); p[1] = 40 * u(rng); p[2] = 6 * u(rng); p[3] = 0; }
+    VoxelHashMap map(1.0, 100.0, 20);
+    if (!map.ctx()) { std::printf("facade: no device\n"); return 0; }
+    if (!map.Empty()) return 2;
+    map.AddPoints(scene);
+    if (map.Empty()) return 3;
+    // source = every 5th scene point shifted by a known translation; identity guess
+    V4d src;
+    for (size_t i = 0; i < scene.size(); i += 5) { Vec4 q = scene[i]; q[0] -= 0.3; q[1] += 0.2; q[2] -= 0.05; src.push_back(q); }
+    Pose guess;
+    const Pose T = RegisterFrameSemantic(src, map, guess, 3.0, 0.3);
+    double p[7];
+    pose_to7(T, p);
+    std::printf("facade pose t = %.6f %.6f %.6f\n", p[4], p[5], p[6]);
+    const bool good = std::fabs(p[4] - 0.3) < 1e-5 && std::fabs(p[5] + 0.2) < 1e-5 && std::fabs(p[6] - 0.05) < 1e-5;
+    // preprocessing + downsample + cluster + graph through the reference's free functions
+    std::vector<Vec3> frame(3000);
+    std::vector<int> label(3000);
+    for (size_t i = 0; i < frame.size(); ++i) { frame[i][0] = 60 * u(rng) - 30; frame[i][1] = 60 * u(rng) - 30; frame[i][2] = 2 * u(rng) - 1.5; label[i] = (int)(rng() % 26); }
+    const V3d_i cropped = PreprocessSemantic(frame, label, 100.0, 5.0);
+    const V3d_i ds = VoxelDownsampleSemantic(cropped, 0.5);
+    V3d_i bg, fg;
+    const std::vector<Bbox> boxes = ClusterPoints(ds.first, ds.second, bg, fg, 2.0, 0.5, 2.0);
+    const Graph g = BuildGraph(boxes, 60.0, 30, 30, 20.0);
+    std::printf("facade cropped %zu ds %zu boxes %zu graph nodes %zu map points %zu\n", cropped.first.size(), ds.first.size(),
+                boxes.size(), g.node_desc.size(), map.Pointcloud().size());
+    std::printf(good && !cropped.first.empty() && ds.first.size() <= cropped.first.size() ? "facade ok\n" : "facade FAILED\n");
+    return good ? 0 : 1;
+}
