@@ -32,14 +32,42 @@ struct QueryResult {
     int probes;      // slot headers inspected
 };
 
-// whole wave cooperates on one query point w (world frame); every lane returns the same result
-__device__ inline QueryResult wave_nearest(const MapView &m, D3 w, int lane) {
-    const K3 kc = voxel_of(w.x, w.y, w.z, m.voxel);
+// trunc(x / voxel) exactly as the reference computes it (C/Coreutils.h:33-37 via fp64 division), but
+// through a multiplication by 1/voxel: x * inv is within 3.4e-16 relative of the correctly rounded
+// quotient, so the truncations agree unless the product sits within that distance of an integer -
+// only then is the ~35-instruction fp64 division paid.
+__device__ inline int32_t voxel_coord_fast(double x, double voxel, double inv) {
+    const double q = x * inv;
+    if (fabs(q - rint(q)) <= fabs(q) * 1e-15) return (int32_t)(x / voxel);
+    return (int32_t)q;
+}
+
+// per-kernel constants of the neighbour search
+struct SearchConst {
+    double inv_voxel;
+    uint32_t cap_magic;  // ceil(2^32 / cap): c / cap == (c * cap_magic) >> 32 for c < 27 * 255
+};
+__device__ inline SearchConst search_const(const MapView &m) {
+    return SearchConst{1.0 / m.voxel, 0xFFFFFFFFu / (uint32_t)m.cap + 1u};
+}
+
+// whole wave cooperates on one query point w (world frame); every lane returns the same result.
+// The wave is alone on its SIMD, so this is bound by instruction count as much as by memory
+// latency: everything per-voxel (slot, count, the query's fp32 position in that voxel's frame) is
+// computed once by the voxel's lane and fetched per candidate with ds_bpermute.
+__device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &sc, D3 w, int lane) {
+    const K3 kc{voxel_coord_fast(w.x, m.voxel, sc.inv_voxel), voxel_coord_fast(w.y, m.voxel, sc.inv_voxel),
+                voxel_coord_fast(w.z, m.voxel, sc.inv_voxel)};
     int slot = -1;
     uint32_t cnt = 0;
     int probes = 0;
+    float relx = 0.f, rely = 0.f, relz = 0.f;
     if (lane < 27) {
         const K3 kn{kc.x + lane / 9 - 1, kc.y + (lane / 3) % 3 - 1, kc.z + lane % 3 - 1};
+        // the query in this voxel's frame (voxel origin = key * voxel_size), rounded to fp32 once
+        relx = (float)(w.x - (double)kn.x * m.voxel);
+        rely = (float)(w.y - (double)kn.y * m.voxel);
+        relz = (float)(w.z - (double)kn.z * m.voxel);
         if (key_in_range(kn)) {
             const unsigned long long pk = pack_key(kn);
             uint32_t s = map_hash(pk) & m.mask;
@@ -61,36 +89,49 @@ __device__ inline QueryResult wave_nearest(const MapView &m, D3 w, int lane) {
     const int nf = __popcll(occmask);
     // stable partition of the lanes: occupied voxels first, in visiting order
     const int before = __popcll(occmask & ((1ull << lane) - 1ull));
-    const int dst = occ ? before : nf + (lane - before);
-    const int c_slot = __builtin_amdgcn_ds_permute(dst << 2, slot);
-    const int c_meta = __builtin_amdgcn_ds_permute(dst << 2, (int)(cnt | ((uint32_t)lane << 8)));
-    // candidates: compacted voxel k, point p  <->  flat index c = k*cap + p
+    const int dst = (occ ? before : nf + (lane - before)) << 2;
+    const int c_slot = __builtin_amdgcn_ds_permute(dst, slot);
+    const int c_meta = __builtin_amdgcn_ds_permute(dst, (int)(cnt | ((uint32_t)lane << 8)));
+    const float c_relx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(relx)));
+    const float c_rely = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(rely)));
+    const float c_relz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(relz)));
+    // candidates: compacted voxel k, point p  <->  flat index c = k*cap + p; three rounds of 64 are
+    // fetched before the first distance is computed
     unsigned long long best = ~0ull;
     float bx = 0.f, by = 0.f, bz = 0.f;
     int blabel = 0;
     int ncand = 0;
     const int total = nf * m.cap;
-    for (int c0 = 0; c0 < total; c0 += 64) {
-        const int c = c0 + lane;
-        const int k = c / m.cap;
-        const int p = c - k * m.cap;
-        const int kk = k < nf ? k : 0;
-        const int es = __shfl(c_slot, kk);
-        const int em = __shfl(c_meta, kk);
-        const int ecnt = em & 0xFF, v = em >> 8;
-        if (k < nf && p < ecnt) {
-            const float4 q = m.pts[(size_t)es * m.cap + p];
-            const double ox = (double)(kc.x + v / 9 - 1) * m.voxel;
-            const double oy = (double)(kc.y + (v / 3) % 3 - 1) * m.voxel;
-            const double oz = (double)(kc.z + v % 3 - 1) * m.voxel;
-            const float dx = q.x - (float)(w.x - ox), dy = q.y - (float)(w.y - oy), dz = q.z - (float)(w.z - oz);
+    constexpr int kRounds = 3;
+    for (int c0 = 0; c0 < total; c0 += 64 * kRounds) {
+        float4 q[kRounds];
+        float rx[kRounds], ry[kRounds], rz[kRounds];
+        int ord[kRounds];  // visiting ordinal v*cap + p of the candidate, -1 = none
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int c = c0 + r * 64 + lane;
+            const int k = (int)__umulhi((uint32_t)c, sc.cap_magic);
+            const int p = c - k * m.cap;
+            const int kk = (k < nf ? k : 0) << 2;
+            const int es = __builtin_amdgcn_ds_bpermute(kk, c_slot);
+            const int em = __builtin_amdgcn_ds_bpermute(kk, c_meta);
+            rx[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_relx)));
+            ry[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_rely)));
+            rz[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_relz)));
+            const bool valid = k < nf && p < (em & 0xFF);
+            ord[r] = valid ? (em >> 8) * m.cap + p : -1;
+            if (valid) q[r] = m.pts[(size_t)es * m.cap + p];
+        }
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            if (ord[r] < 0) continue;
+            const float dx = q[r].x - rx[r], dy = q[r].y - ry[r], dz = q[r].z - rz[r];
             const float d2 = dx * dx + (dy * dy + dz * dz);
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)(v * m.cap + p);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)ord[r];
             if (key < best) {
                 best = key;
-                bx = q.x; by = q.y; bz = q.z;
-                blabel = __float_as_int(q.w);
+                bx = q[r].x; by = q[r].y; bz = q[r].z;
+                blabel = __float_as_int(q[r].w);
             }
             ++ncand;
         }
@@ -116,38 +157,259 @@ __device__ inline QueryResult wave_nearest(const MapView &m, D3 w, int lane) {
         const int winner = __ffsll((long long)__ballot(best == wbest)) - 1;
         const float fx = __shfl(bx, winner), fy = __shfl(by, winner), fz = __shfl(bz, winner);
         r.label = __shfl(blabel, winner);
-        const int v = (int)(wbest & 0xFFFFFFFFull) / m.cap;
+        const int v = (int)__umulhi((uint32_t)(wbest & 0xFFFFFFFFull), sc.cap_magic);
         r.target = D3{(double)(kc.x + v / 9 - 1) * m.voxel + (double)fx, (double)(kc.y + (v / 3) % 3 - 1) * m.voxel + (double)fy,
                       (double)(kc.z + v % 3 - 1) * m.voxel + (double)fz};
     }
     return r;
 }
 
-__global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(MapView m, CloudView src,
-                                                                     const int32_t *__restrict__ n_ptr, DevState *st,
-                                                                     double *__restrict__ partials) {
+// fixed-order fold of the per-block partials ([scalar][block] layout, kIcpBlocks columns): each
+// wave folds whole rows - ALL its loads issued before the first use, so the fold costs one memory
+// round trip - then a shuffle tree; the order is fixed, so the result is bit-reproducible.  The loads
+// are agent-scope atomics: inside the fused kernel the rows were written by blocks on other XCDs,
+// whose L2 is not this one's.
+template <int NWAVES>
+__device__ inline void fold_partials(const double *partials, double *out /*shared [kIcpSums]*/) {
+    static_assert(kIcpBlocks % 64 == 0, "one column per lane and load");
+    constexpr int kRows = (kIcpSums + NWAVES - 1) / NWAVES, kCols = kIcpBlocks / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double v[kRows][kCols];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int sc = wave + r * NWAVES;
+#pragma unroll
+        for (int c = 0; c < kCols; ++c)
+            v[r][c] = sc < kIcpSums ? __hip_atomic_load(&partials[(size_t)sc * kIcpBlocks + c * 64 + lane],
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int sc = wave + r * NWAVES;
+        double sum = v[r][0];
+#pragma unroll
+        for (int c = 1; c < kCols; ++c) sum += v[r][c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        if (lane == 0 && sc < kIcpSums) out[sc] = sum;
+    }
+    __syncthreads();
+}
+
+// A (row-major 6x6) and b of the Gauss-Newton system from the 16 moment sums (J = [I | -hat(s)])
+__device__ inline void normal_equations(const double *S, double *A /*[36]*/, double *b /*[6]*/) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = 0.0;
+    const double W = S[0], sx = S[1], sy = S[2], sz = S[3];
+    const double xx = S[4], yy = S[5], zz = S[6], xy = S[7], xz = S[8], yz = S[9];
+    A[0] = A[7] = A[14] = W;
+    // sum w * (-hat(s)) and its transpose
+    A[0 * 6 + 4] = sz;  A[0 * 6 + 5] = -sy;
+    A[1 * 6 + 3] = -sz; A[1 * 6 + 5] = sx;
+    A[2 * 6 + 3] = sy;  A[2 * 6 + 4] = -sx;
+    A[4 * 6 + 0] = sz;  A[5 * 6 + 0] = -sy;
+    A[3 * 6 + 1] = -sz; A[5 * 6 + 1] = sx;
+    A[3 * 6 + 2] = sy;  A[4 * 6 + 2] = -sx;
+    // sum w * (|s|^2 I - s s^T)
+    A[3 * 6 + 3] = yy + zz; A[4 * 6 + 4] = xx + zz; A[5 * 6 + 5] = xx + yy;
+    A[3 * 6 + 4] = A[4 * 6 + 3] = -xy;
+    A[3 * 6 + 5] = A[5 * 6 + 3] = -xz;
+    A[4 * 6 + 5] = A[5 * 6 + 4] = -yz;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = S[10 + i];
+}
+
+// LDS words of the solve tail
+struct SolveLds {
+    double A[36];
+    double rhs[6];
+    double x[6];
+};
+
+// order LDS traffic between lanes of ONE wave (LDS operations of a wave execute in order; this only
+// keeps the compiler from moving them and waits for the data)
+__device__ inline void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Wave-parallel 6x6 symmetric solve A x = rhs, the LDLT of F/Registration.cpp:111 (Eigen's
+// `JTJ.ldlt().solve(-JTr)`): lane 6*i+j owns element (i,j) of the permuted matrix.
+//  * Pivoting: Eigen's left-looking LDLT picks the k-th pivot as the first largest |diagonal| among
+//    rows k..5 of the matrix as permuted so far - those diagonal entries are still the ORIGINAL ones,
+//    so the whole pivot sequence is a selection sort of the original diagonal.  Every lane replays
+//    that sort (uniform, in registers) and loads its element of B = P A P^T from LDS.
+//  * Factorisation: right-looking rank-1 updates with ds_bpermute broadcasts of column k; one
+//    reciprocal per pivot.  A zero pivot leaves its column undivided and contributes nothing, a
+//    |D_i| <= DBL_MIN gives x_i = 0 (Eigen's pseudo-inverse rule), an all-zero system gives x = 0.
+//  * The two triangular solves broadcast one unknown per step.
+// Straight-line serial code for this (36-entry matrix in registers, constant indices) is ~2500
+// dependent fp64 instructions fetched cold once per launch and measured >10 us; this is ~10x
+// shorter.  Rounding differs from Eigen's operation order by ulps (pose bar: 1e-4 m / 1e-5 rad).
+__device__ inline void wave_solve6(SolveLds &L, int lane) {
+    // --- pivot sequence: selection sort (first maximum wins) on |diag| ---
+    double mag[6];
+    int id[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { mag[i] = fabs(L.A[i * 7]); id[i] = i; }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        double best = mag[k];
+        int p = k;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i)
+            if (mag[i] > best) { best = mag[i]; p = i; }
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {  // swap entries k and p through selects (constant indices)
+            const bool hit = (p == i);
+            const double mk = mag[k], mi = mag[i];
+            mag[k] = hit ? mi : mk; mag[i] = hit ? mk : mi;
+            const int ik = id[k], ii = id[i];
+            id[k] = hit ? ii : ik; id[i] = hit ? ik : ii;
+        }
+    }
+    const int l36 = lane < 36 ? lane : 35;
+    const int i = l36 / 6, j = l36 - 6 * i;
+    int pi = id[0], pj = id[0];
+#pragma unroll
+    for (int t = 1; t < 6; ++t) { pi = (i == t) ? id[t] : pi; pj = (j == t) ? id[t] : pj; }
+    double B = L.A[pi * 6 + pj];
+    double y = L.rhs[pi];
+    // --- right-looking LDL^T ---
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double dk = __shfl(B, k * 7);
+        const bool valid = fabs(dk) > 0.0;
+        const double r = valid ? 1.0 / dk : 0.0;
+        const double cik = __shfl(B, i * 6 + k), cjk = __shfl(B, j * 6 + k);
+        const double lik = valid ? cik * r : cik;
+        if (i > k && j > k) B -= valid ? lik * cjk : 0.0;
+        if (i > k && j == k) B = lik;
+    }
+    // --- forward substitution: y <- L^-1 y (every lane of row i carries y_i) ---
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double yk = __shfl(y, k * 7);
+        const double lik = __shfl(B, i * 6 + k);
+        if (i > k) y -= lik * yk;
+    }
+    // --- D^+ ---
+    {
+        const double di = __shfl(B, i * 7);
+        y = (fabs(di) > 2.2250738585072014e-308) ? y / di : 0.0;
+    }
+    // --- backward substitution: y <- L^-T y ---
+#pragma unroll
+    for (int k = 5; k > 0; --k) {
+        const double yk = __shfl(y, k * 7);
+        const double lki = __shfl(B, k * 6 + i);
+        if (i < k) y -= lki * yk;
+    }
+    // x = P^T y
+    if (lane < 36 && i == j) L.x[pi] = y;
+}
+
+// 6x6 solve + SE3 update + convergence test of one Gauss-Newton iteration (F/Registration.cpp:
+// 111-112,165-172), run by wave 0 of the folding block.  mailbox: 4 ints in host-pinned,
+// device-mapped memory {iterations finished, done, -, -}; the host polls it instead of a copy +
+// stream sync.
+struct TailState {  // what the solve tail reads from DevState, fetched before the fold so the loads overlap it
+    Rigid T_icp, guess;
+    long long corr, cand, probe;
+    int32_t iter, max_iter;
+};
+__device__ inline TailState load_tail_state(const DevState *st) {
+    return TailState{st->T_icp, st->guess, st->icp_corr, st->icp_cand, st->icp_probe, st->icp_iter, st->icp_max_iter};
+}
+
+__device__ inline void solve_and_update(DevState *st, const TailState &ts, const double *S, SolveLds &L, int lane,
+                                        int32_t *mailbox) {
+    if (lane == 0) {
+        double b[6];
+        normal_equations(S, L.A, b);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) L.rhs[i] = -b[i];
+    }
+    wave_lds_sync();
+    wave_solve6(L, lane);
+    wave_lds_sync();
+    if (lane != 0) return;
+    double x[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = L.x[i];
+    const Rigid est = rigid_exp_small(D3{x[0], x[1], x[2]}, D3{x[3], x[4], x[5]});
+    const Rigid T_icp = compose_fast(est, ts.T_icp);
+    st->T_icp = T_icp;
+    st->T_total = compose_fast(T_icp, ts.guess);
+    st->icp_corr = ts.corr + (long long)S[16];
+    st->icp_cand = ts.cand + (long long)S[17];
+    st->icp_probe = ts.probe + (long long)S[18];
+    const int it = ts.iter + 1;
+    st->icp_iter = it;
+    // estimation.log().norm() < 1e-4 (F/Registration.cpp:169): log(exp(x)) == x for |omega| < pi, so
+    // the squared 6-vector norm of the update itself is compared with 1e-8
+    double nn = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
+    const int done = (nn < 1e-8 || it >= ts.max_iter) ? 1 : 0;
+    if (done) st->icp_done = 1;
+    st->icp_ticket = 0;
+    if (mailbox) {
+        __hip_atomic_store(&mailbox[0], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mailbox[1], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// One Gauss-Newton iteration.  Every block reduces its queries to kIcpSums partial sums; with
+// fuse != 0 the block that publishes LAST (ticket counter in DevState) folds all partials in fixed
+// order and runs the solve, so an iteration is a single dispatch.  The fold order does not depend on
+// which block happens to be last, so results stay bit-reproducible.
+// Cross-block visibility: the partials are written and read with agent-scope atomics (they bypass
+// the per-XCD L2), and wave 0 - which issues both the partial stores and the ticket increment -
+// orders them with the increment's release.  A __threadfence() by all 512 threads here measured
+// +29 us per launch.
+__global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, CloudView src, int src_cap,
+                                                                    const int32_t *__restrict__ n_ptr, DevState *st,
+                                                                    double *partials, int fuse, int32_t *mailbox) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int waves_per_block = kIcpThreads / 64;
+    // the first query's coordinates are fetched before anything is known about the state (the arrays
+    // hold src_cap elements whatever n is), so this load overlaps the state loads
+    int q = blockIdx.x * waves_per_block + wave;
+    const int qs = q < src_cap ? q : src_cap - 1;
+    D3 p{src.x[qs], src.y[qs], src.z[qs]};
+    int label = src.l[qs];
     if (st->icp_done) return;
     const int n = *n_ptr;
     const Rigid T = st->T_total;
     const double max_corr = st->max_corr, th = st->kernel_th;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int waves_per_block = kIcpThreads / 64;
+    const SearchConst sc = search_const(m);
+    const double max_corr2 = max_corr * max_corr, th2 = th * th;
     double acc[kIcpSums];
 #pragma unroll
     for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
-    for (int q = blockIdx.x * waves_per_block + wave; q < n; q += gridDim.x * waves_per_block) {
-        const D3 s = apply(T, D3{src.x[q], src.y[q], src.z[q]});
-        const int label = src.l[q];
-        const QueryResult r = wave_nearest(m, s, lane);
+    while (q < n) {
+        const D3 s = apply(T, p);
+        const int lab = label;
+        q += gridDim.x * waves_per_block;
+        if (q < n) {
+            p = D3{src.x[q], src.y[q], src.z[q]};
+            label = src.l[q];
+        }
+        const QueryResult r = wave_nearest(m, sc, s, lane);
         acc[17] += (double)r.candidates;
         acc[18] += (double)r.probes;
         if (!r.found) continue;
         const D3 res = sub(s, r.target);
         const double r2 = sq3(res);
-        if (!(sqrt(r2) < max_corr)) continue;
-        const double wgt = (th * th) / ((th + r2) * (th + r2));
-        const double ws = wgt * semantic_weight(label);
+        // |res| < max_corr (F/VoxelHashMap.cpp:120-125) compared in squares: differs from the
+        // reference's sqrt form only for a residual within an ulp of the limit
+        if (!(r2 < max_corr2)) continue;
+        const double wgt = th2 / ((th + r2) * (th + r2));
+        const double ws = wgt * semantic_weight(lab);
         acc[0] += wgt;
         acc[1] += wgt * s.x; acc[2] += wgt * s.y; acc[3] += wgt * s.z;
         acc[4] += wgt * s.x * s.x; acc[5] += wgt * s.y * s.y; acc[6] += wgt * s.z * s.z;
@@ -158,99 +420,49 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(MapView m, 
         acc[16] += 1.0;
     }
     __shared__ double red[kIcpThreads / 64][kIcpSums];
+    __shared__ double S[kIcpSums];
+    __shared__ SolveLds solve_lds;
+    __shared__ int is_last;
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) red[wave][k] = acc[k];
     }
     __syncthreads();
-    if (threadIdx.x < kIcpSums) {
-        double sum = 0.0;
+    if (wave != 0) {
+        if (!fuse) return;
+    } else {
+        if (lane < kIcpSums) {
+            double sum = 0.0;
 #pragma unroll
-        for (int w = 0; w < kIcpThreads / 64; ++w) sum += red[w][threadIdx.x];
-        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sum;  // [scalar][block]: the fold reads rows
-    }
-}
-
-// fixed-order fold of the per-block partials ([scalar][block] layout): each wave folds whole rows
-// with independent coalesced loads + a shuffle tree, so the result is bit-reproducible
-__device__ inline void fold_partials(const double *__restrict__ partials, int nblocks, double *out /*shared [kIcpSums]*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int sc = wave; sc < kIcpSums; sc += nwaves) {
-        double sum = 0.0;
-        for (int b = lane; b < nblocks; b += 64) sum += partials[(size_t)sc * nblocks + b];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
-        if (lane == 0) out[sc] = sum;
+            for (int w = 0; w < kIcpThreads / 64; ++w) sum += red[w][lane];
+            // [scalar][block]: the fold reads rows
+            __hip_atomic_store(&partials[(size_t)lane * gridDim.x + blockIdx.x], sum, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!fuse) return;
+        if (lane == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(&st->icp_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = (t == gridDim.x - 1) ? 1 : 0;
+        }
     }
     __syncthreads();
+    if (!is_last) return;
+    TailState ts{};
+    if (wave == 0) ts = load_tail_state(st);
+    fold_partials<kIcpThreads / 64>(partials, S);
+    if (wave == 0) solve_and_update(st, ts, S, solve_lds, lane, mailbox);
 }
 
-__device__ inline void normal_equations(const double *S, double A[6][6], double b[6]) {
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) A[i][j] = 0.0;
-    const double W = S[0], sx = S[1], sy = S[2], sz = S[3];
-    const double xx = S[4], yy = S[5], zz = S[6], xy = S[7], xz = S[8], yz = S[9];
-    A[0][0] = A[1][1] = A[2][2] = W;
-    // sum w * (-hat(s)) and its transpose
-    A[0][4] = sz;  A[0][5] = -sy;
-    A[1][3] = -sz; A[1][5] = sx;
-    A[2][3] = sy;  A[2][4] = -sx;
-    A[4][0] = sz;  A[5][0] = -sy;
-    A[3][1] = -sz; A[5][1] = sx;
-    A[3][2] = sy;  A[4][2] = -sx;
-    // sum w * (|s|^2 I - s s^T)
-    A[3][3] = yy + zz; A[4][4] = xx + zz; A[5][5] = xx + yy;
-    A[3][4] = A[4][3] = -xy;
-    A[3][5] = A[5][3] = -xz;
-    A[4][5] = A[5][4] = -yz;
-    for (int i = 0; i < 6; ++i) b[i] = S[10 + i];
-}
-
-// mailbox: 4 ints in host-pinned, device-mapped memory {iterations finished, done, -, -}; the host
-// polls it instead of issuing a copy + stream sync per chunk of iterations
-__global__ __launch_bounds__(256) void icp_solve_kernel(DevState *st, const double *__restrict__ partials, int nblocks,
-                                                        int32_t *mailbox) {
-    if (st->icp_done) return;
-    __shared__ double S[kIcpSums];
-    fold_partials(partials, nblocks, S);
-    if (threadIdx.x != 0) return;
-    double A[6][6], b[6], rhs[6], x[6];
-    normal_equations(S, A, b);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) rhs[i] = -b[i];
-    solve6_static(A, rhs, x);
-    const Rigid est = rigid_exp_small(x);
-    const Rigid T_icp = compose(est, st->T_icp);
-    st->T_icp = T_icp;
-    st->T_total = compose(T_icp, st->guess);
-    st->icp_corr += (long long)S[16];
-    st->icp_cand += (long long)S[17];
-    st->icp_probe += (long long)S[18];
-    const int it = st->icp_iter + 1;
-    st->icp_iter = it;
-    // estimation.log().norm() (F/Registration.cpp:169): log(exp(x)) == x for |omega| < pi, so the
-    // 6-vector norm of the update itself is the termination quantity
-    double nn = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
-    const int done = (sqrt(nn) < 0.0001 || it >= st->icp_max_iter) ? 1 : 0;
-    if (done) st->icp_done = 1;
-    if (mailbox) {
-        __hip_atomic_store(&mailbox[0], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mailbox[1], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-__global__ __launch_bounds__(256) void icp_finish_kernel(DevState *st, const double *__restrict__ partials, int nblocks,
+__global__ __launch_bounds__(256) void icp_finish_kernel(DevState *st, const double *partials, int nblocks,
                                                          double *__restrict__ out28) {
     __shared__ double S[kIcpSums];
-    fold_partials(partials, nblocks, S);
+    fold_partials<4>(partials, S);
     if (threadIdx.x != 0) return;
-    double A[6][6], b[6];
+    double A[36], b[6];
     normal_equations(S, A, b);
     int k = 0;
     for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) out28[k++] = A[i][j];
+        for (int j = i; j < 6; ++j) out28[k++] = A[i * 6 + j];
     for (int i = 0; i < 6; ++i) out28[k++] = b[i];
     out28[27] = S[16];
     st->icp_cand += (long long)S[17];
@@ -266,6 +478,7 @@ __global__ void icp_init_kernel(DevState *st, Rigid guess, double max_corr, doub
     st->icp_iter = 0;
     st->icp_done = 0;
     st->icp_max_iter = max_iter;
+    st->icp_ticket = 0;
     st->icp_corr = 0;
     st->icp_cand = 0;
     st->icp_probe = 0;
@@ -276,9 +489,10 @@ __global__ __launch_bounds__(256) void correspondences_kernel(MapView m, CloudVi
                                                               double *__restrict__ tgt_xyzl, int32_t *__restrict__ found) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SearchConst sc = search_const(m);
     for (int q = blockIdx.x * 4 + wave; q < n; q += gridDim.x * 4) {
         const D3 s{src.x[q], src.y[q], src.z[q]};
-        const QueryResult r = wave_nearest(m, s, lane);
+        const QueryResult r = wave_nearest(m, sc, s, lane);
         bool ok = false;
         if (r.found) ok = sqrt(sq3(sub(r.target, s))) < max_dist;
         if (lane == 0) {
@@ -296,14 +510,10 @@ void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max
     hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, s, st, guess, max_corr, kernel_th, max_iter);
 }
 
-void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, const int32_t *n_ptr, DevState *st, double *partials,
-                          bool solve, int32_t *mailbox) {
-    hipLaunchKernelGGL(icp_accumulate_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, n_ptr, st, partials);
-    if (solve) hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, st, partials, kIcpBlocks, mailbox);
-}
-
-void launch_icp_iteration_solve_only(hipStream_t s, DevState *st, double *partials, int32_t *mailbox) {
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, s, st, partials, kIcpBlocks, mailbox);
+void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
+                          double *partials, bool solve, int32_t *mailbox) {
+    hipLaunchKernelGGL(icp_iteration_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st,
+                       partials, solve ? 1 : 0, mailbox);
 }
 
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out28_dev) {

@@ -361,11 +361,10 @@ int enqueue_icp_iteration(sgs_ctx *c, CloudView src, const int32_t *n_ptr) {
         }
         auto &ev = c->icp_events[c->icp_events_used++];
         SGS_HIP(c, hipEventRecord(ev.first, c->stream));
-        launch_icp_iteration(c->stream, c->map.v, src, n_ptr, c->st, c->partials, false, nullptr);
+        launch_icp_iteration(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, true, c->mailbox_dev);
         SGS_HIP(c, hipEventRecord(ev.second, c->stream));
-        launch_icp_iteration_solve_only(c->stream, c->st, c->partials, c->mailbox_dev);
     } else {
-        launch_icp_iteration(c->stream, c->map.v, src, n_ptr, c->st, c->partials, true, c->mailbox_dev);
+        launch_icp_iteration(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, true, c->mailbox_dev);
     }
     return SGS_OK;
 }
@@ -966,7 +965,7 @@ int sgs_build_linear_system(sgs_ctx *c, const double *xyzl_world, int n, double 
     int r;
     if ((r = upload_xyzl(c, xyzl_world, n, c->aux))) return r;  // aux_n[0] = n
     launch_icp_init(c->stream, c->st, rigid_identity(), max_distance, kernel, 1, 1);
-    launch_icp_iteration(c->stream, c->map.v, c->aux, &c->aux_n[0], c->st, c->partials, false, nullptr);
+    launch_icp_iteration(c->stream, c->map.v, c->aux, c->N, &c->aux_n[0], c->st, c->partials, false, nullptr);
     launch_linear_system_finish(c->stream, c->st, c->partials, c->out28);
     double h[28];
     SGS_HIP(c, hipMemcpyAsync(h, c->out28, sizeof(h), hipMemcpyDeviceToHost, c->stream));

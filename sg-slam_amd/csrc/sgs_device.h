@@ -57,8 +57,8 @@ struct MapView {
 };
 
 constexpr int kIcpSums = 20;  // 16 moment sums + n_corr + candidates + probes + spare
-constexpr int kIcpBlocks = 256;
-constexpr int kIcpThreads = 512;
+constexpr int kIcpBlocks = 256;     // x 4 waves = 1024 queries in flight, one wavefront each and at most one
+constexpr int kIcpThreads = 256;    // wavefront per SIMD: the per-query work is a serial instruction stream
 
 struct DevState {
     // cloud sizes
@@ -68,7 +68,8 @@ struct DevState {
     // registration
     Rigid guess, T_icp, T_total;
     double max_corr, kernel_th;
-    int32_t icp_iter, icp_done, icp_max_iter, pad0;
+    int32_t icp_iter, icp_done, icp_max_iter;
+    uint32_t icp_ticket;  // blocks of the running accumulate kernel that have published their partials
     long long icp_corr, icp_cand, icp_probe;
     // map
     int32_t map_live, map_tomb, map_points, pad1;
@@ -110,11 +111,13 @@ void launch_map_clear(hipStream_t s, MapView m, DevState *st);
 // ---- k_icp.hip ----
 void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max_corr, double kernel_th,
                      int max_iter, int prior_world /*1: source already in world frame*/);
-// one Gauss-Newton iteration = fused correspondence search + linear-system reduction, then solve.
-// corr_* (optional) receive per-query results for sgs_map_get_correspondences.
-void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, const int32_t *n_ptr, DevState *st,
-                          double *partials, bool solve, int32_t *mailbox /*host-mapped, nullable*/);
-void launch_icp_iteration_solve_only(hipStream_t s, DevState *st, double *partials, int32_t *mailbox);
+// one Gauss-Newton iteration in ONE kernel: fused correspondence search + linear-system reduction;
+// with solve=true the last block to publish its partials folds them and runs the 6x6 solve + pose
+// update + convergence test (no second dispatch).  solve=false leaves the partials for
+// launch_linear_system_finish.
+void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap /*elements allocated, >= 1*/,
+                          const int32_t *n_ptr, DevState *st, double *partials, bool solve,
+                          int32_t *mailbox /*host-mapped, nullable*/);
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
                             int32_t *found);
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out27_dev);

@@ -128,58 +128,12 @@ SGS_HD double rigid_rotation_angle(const Rigid &T) {
 
 // Symmetric 6x6 solve A x = b by LDL^T with diagonal pivoting; pivots at or below DBL_MIN are
 // treated as zero (pseudo-inverse), so an all-zero system yields x = 0 as Eigen's LDLT does
-// (F/Registration.cpp:111).  A is overwritten.
-SGS_HD void solve6(double A[6][6], const double *b, double *x) {
-    int tr[6];
-    bool zero = false;
-    for (int k = 0; k < 6; ++k) {
-        tr[k] = k;
-        if (zero) continue;
-        int p = k;
-        double best = fabs(A[k][k]);
-        for (int i = k + 1; i < 6; ++i) {
-            const double v = fabs(A[i][i]);
-            if (v > best) { best = v; p = i; }
-        }
-        tr[k] = p;
-        if (p != k) {
-            for (int j = 0; j < k; ++j) { const double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
-            for (int i = p + 1; i < 6; ++i) { const double t = A[i][k]; A[i][k] = A[i][p]; A[i][p] = t; }
-            { const double t = A[k][k]; A[k][k] = A[p][p]; A[p][p] = t; }
-            for (int i = k + 1; i < p; ++i) { const double t = A[i][k]; A[i][k] = A[p][i]; A[p][i] = t; }
-        }
-        double tmp[6];
-        for (int j = 0; j < k; ++j) tmp[j] = A[j][j] * A[k][j];
-        if (k > 0) {
-            double s = 0;
-            for (int j = 0; j < k; ++j) s += A[k][j] * tmp[j];
-            A[k][k] -= s;
-            for (int i = k + 1; i < 6; ++i) {
-                double s2 = 0;
-                for (int j = 0; j < k; ++j) s2 += A[i][j] * tmp[j];
-                A[i][k] -= s2;
-            }
-        }
-        const double akk = A[k][k];
-        if (k == 0 && !(fabs(akk) > 0.0)) { zero = true; continue; }
-        if (fabs(akk) > 0.0)
-            for (int i = k + 1; i < 6; ++i) A[i][k] /= akk;
-    }
-    double y[6];
-    for (int i = 0; i < 6; ++i) y[i] = b[i];
-    for (int k = 0; k < 6; ++k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < i; ++j) y[i] -= A[i][j] * y[j];
-    for (int i = 0; i < 6; ++i) y[i] = (fabs(A[i][i]) > 2.2250738585072014e-308) ? y[i] / A[i][i] : 0.0;
-    for (int i = 5; i >= 0; --i)
-        for (int j = i + 1; j < 6; ++j) y[i] -= A[j][i] * y[j];
-    for (int k = 5; k >= 0; --k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
-    for (int i = 0; i < 6; ++i) x[i] = y[i];
-}
-
-// Same algorithm as solve6 with every index a compile-time constant (the pivot is dispatched through
-// if-chains over constant cases), so the 6x6 system lives in registers on the GPU instead of in
-// scratch memory: a runtime-indexed private array costs a memory round trip per access.
+// (F/Registration.cpp:111).  A is overwritten.  Every index is a compile-time constant (the pivot
+// is dispatched through if-chains over constant cases), so the 6x6 system lives in registers on the
+// GPU instead of in scratch memory: a runtime-indexed private array costs a memory round trip per
+// access.  Each column is scaled by ONE reciprocal of its pivot (an fp64 divide is a ~30-instruction
+// dependent chain on CDNA and this runs on a single lane); that differs from Eigen's per-element
+// divide by an ulp, far inside the 1e-4 m / 1e-5 rad pose bar.
 namespace detail {
 template <int K, int P>
 SGS_HD void sym_swap(double (&A)[6][6]) {
@@ -199,17 +153,22 @@ SGS_HD void pivot_swap(double (&A)[6][6], int p) {
     if constexpr (K + 4 < 6) { if (p == K + 4) sym_swap<K, K + 4>(A); }
     if constexpr (K + 5 < 6) { if (p == K + 5) sym_swap<K, K + 5>(A); }
 }
+// swap y[K] <-> y[p] (p >= K) as branch-free selects over constant indices: an if-chain here gets
+// its stores sunk into one store through a phi of addresses, which turns y into a scratch array
 template <int K>
 SGS_HD void vec_swap(double (&y)[6], int p) {
-    if constexpr (K + 1 < 6) { if (p == K + 1) { const double t = y[K]; y[K] = y[K + 1]; y[K + 1] = t; } }
-    if constexpr (K + 2 < 6) { if (p == K + 2) { const double t = y[K]; y[K] = y[K + 2]; y[K + 2] = t; } }
-    if constexpr (K + 3 < 6) { if (p == K + 3) { const double t = y[K]; y[K] = y[K + 3]; y[K + 3] = t; } }
-    if constexpr (K + 4 < 6) { if (p == K + 4) { const double t = y[K]; y[K] = y[K + 4]; y[K + 4] = t; } }
-    if constexpr (K + 5 < 6) { if (p == K + 5) { const double t = y[K]; y[K] = y[K + 5]; y[K + 5] = t; } }
+#pragma unroll
+    for (int j = K + 1; j < 6; ++j) {
+        const bool hit = (p == j);
+        const double yk = y[K], yj = y[j];
+        y[K] = hit ? yj : yk;
+        y[j] = hit ? yk : yj;
+    }
 }
 template <int K>
-SGS_HD void ldlt_column(double (&A)[6][6], int (&tr)[6], bool &zero) {
+SGS_HD void ldlt_column(double (&A)[6][6], int (&tr)[6], double (&inv)[6], bool &zero) {
     tr[K] = K;
+    inv[K] = 0.0;
     if (zero) return;
     int p = K;
     double best = fabs(A[K][K]);
@@ -239,21 +198,24 @@ SGS_HD void ldlt_column(double (&A)[6][6], int (&tr)[6], bool &zero) {
     const double akk = A[K][K];
     if (K == 0 && !(fabs(akk) > 0.0)) { zero = true; return; }
     if (fabs(akk) > 0.0) {
+        const double r = 1.0 / akk;
+        if (fabs(akk) > 2.2250738585072014e-308) inv[K] = r;
 #pragma unroll
-        for (int i = K + 1; i < 6; ++i) A[i][K] /= akk;
+        for (int i = K + 1; i < 6; ++i) A[i][K] *= r;
     }
 }
 }  // namespace detail
 
 SGS_HD void solve6_static(double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
     int tr[6];
+    double inv[6];
     bool zero = false;
-    detail::ldlt_column<0>(A, tr, zero);
-    detail::ldlt_column<1>(A, tr, zero);
-    detail::ldlt_column<2>(A, tr, zero);
-    detail::ldlt_column<3>(A, tr, zero);
-    detail::ldlt_column<4>(A, tr, zero);
-    detail::ldlt_column<5>(A, tr, zero);
+    detail::ldlt_column<0>(A, tr, inv, zero);
+    detail::ldlt_column<1>(A, tr, inv, zero);
+    detail::ldlt_column<2>(A, tr, inv, zero);
+    detail::ldlt_column<3>(A, tr, inv, zero);
+    detail::ldlt_column<4>(A, tr, inv, zero);
+    detail::ldlt_column<5>(A, tr, inv, zero);
     double y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) y[i] = b[i];
@@ -264,7 +226,7 @@ SGS_HD void solve6_static(double (&A)[6][6], const double (&b)[6], double (&x)[6
 #pragma unroll
         for (int j = 0; j < i; ++j) y[i] -= A[i][j] * y[j];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) y[i] = (fabs(A[i][i]) > 2.2250738585072014e-308) ? y[i] / A[i][i] : 0.0;
+    for (int i = 0; i < 6; ++i) y[i] *= inv[i];  // inv == 0 where |D_i| <= DBL_MIN (pseudo-inverse)
 #pragma unroll
     for (int i = 5; i >= 0; --i)
 #pragma unroll
@@ -275,29 +237,54 @@ SGS_HD void solve6_static(double (&A)[6][6], const double (&b)[6], double (&x)[6
     for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
-// exp for the small Gauss-Newton updates on the device: one sincos of theta/2, the full-angle terms
-// from double-angle identities (differs from rigid_exp by rounding only)
-SGS_HD Rigid rigid_exp_small(const double *a) {
-    const D3 v{a[0], a[1], a[2]}, w{a[3], a[4], a[5]};
+// exp for the Gauss-Newton updates on the device.  The updates are small (|omega| well below 0.1 rad
+// after the first iteration), so below |omega|^2 = 1e-2 every trigonometric coefficient is a short
+// even power series in theta (no sqrt, no sincos, no cancellation; truncation < 1e-19 relative);
+// above it, one sincos of theta/2 plus double-angle identities.  Differs from rigid_exp by rounding.
+SGS_HD Rigid rigid_exp_small(D3 v, D3 w) {
     const double th2 = sq3(w);
-    if (th2 < kTiny * kTiny) return rigid_exp(a);
-    const double theta = sqrt(th2);
-    const double h = 0.5 * theta;
-    double sh, ch;
-    sincos(h, &sh, &ch);
-    const double im = sh / theta;
+    double im, re, c1, c2;
+    if (th2 < 1e-2) {
+        const double h2 = 0.25 * th2;
+        // sin(h)/theta = 0.5 * sin(h)/h ; cos(h)
+        im = 0.5 * (1.0 + h2 * (-1.0 / 6 + h2 * (1.0 / 120 + h2 * (-1.0 / 5040 + h2 * (1.0 / 362880 +
+                   h2 * (-1.0 / 39916800 + h2 * (1.0 / 6227020800.0)))))));
+        re = 1.0 + h2 * (-1.0 / 2 + h2 * (1.0 / 24 + h2 * (-1.0 / 720 + h2 * (1.0 / 40320 +
+                   h2 * (-1.0 / 3628800 + h2 * (1.0 / 479001600.0))))));
+        // (1 - cos t)/t^2 ; (t - sin t)/t^3
+        c1 = 1.0 / 2 + th2 * (-1.0 / 24 + th2 * (1.0 / 720 + th2 * (-1.0 / 40320 + th2 * (1.0 / 3628800 +
+                   th2 * (-1.0 / 479001600.0 + th2 * (1.0 / 87178291200.0))))));
+        c2 = 1.0 / 6 + th2 * (-1.0 / 120 + th2 * (1.0 / 5040 + th2 * (-1.0 / 362880 + th2 * (1.0 / 39916800 +
+                   th2 * (-1.0 / 6227020800.0 + th2 * (1.0 / 1307674368000.0))))));
+    } else {
+        const double theta = sqrt(th2);
+        double sh, ch;
+        sincos(0.5 * theta, &sh, &ch);
+        im = sh / theta;
+        re = ch;
+        c1 = 2.0 * sh * sh / th2;                          // 1 - cos(theta) = 2 sin^2(theta/2)
+        c2 = (theta - 2.0 * sh * ch) / (th2 * theta);
+    }
     Rigid T;
-    T.qw = ch; T.qx = im * w.x; T.qy = im * w.y; T.qz = im * w.z;
-    const double n = sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
-    T.qw /= n; T.qx /= n; T.qy /= n; T.qz /= n;
-    const double one_minus_cos = 2.0 * sh * sh;     // 1 - cos(theta)
-    const double sin_theta = 2.0 * sh * ch;
-    const double c1 = one_minus_cos / th2;
-    const double c2 = (theta - sin_theta) / (th2 * theta);
+    T.qw = re; T.qx = im * w.x; T.qy = im * w.y; T.qz = im * w.z;
+    const double rn = 1.0 / sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
+    T.qw *= rn; T.qx *= rn; T.qy *= rn; T.qz *= rn;
     const D3 wv = crs(w, v);
     const D3 wwv = crs(w, wv);
     T.t = add(v, add(scale(c1, wv), scale(c2, wwv)));
     return T;
+}
+// compose() with the renormalisation as one reciprocal (device solve tail)
+SGS_HD Rigid compose_fast(const Rigid &a, const Rigid &b) {
+    Rigid r;
+    r.qw = a.qw * b.qw - a.qx * b.qx - a.qy * b.qy - a.qz * b.qz;
+    r.qx = a.qw * b.qx + a.qx * b.qw + a.qy * b.qz - a.qz * b.qy;
+    r.qy = a.qw * b.qy + a.qy * b.qw + a.qz * b.qx - a.qx * b.qz;
+    r.qz = a.qw * b.qz + a.qz * b.qw + a.qx * b.qy - a.qy * b.qx;
+    const double rn = 1.0 / sqrt(r.qw * r.qw + r.qx * r.qx + r.qy * r.qy + r.qz * r.qz);
+    r.qw *= rn; r.qx *= rn; r.qy *= rn; r.qz *= rn;
+    r.t = add(a.t, rotate(a, b.t));
+    return r;
 }
 
 // ---- voxel keys ----
