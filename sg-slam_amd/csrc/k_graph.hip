@@ -71,39 +71,58 @@ __global__ __launch_bounds__(kBlock) void route_count_kernel(CloudView in, const
     if (threadIdx.x < 8) blockcnt[blockIdx.x * 8 + threadIdx.x] = cnt[threadIdx.x];
 }
 
-// exclusive per-category prefix over blocks (in place) + totals + class parameters
+// exclusive per-category prefix over blocks (in place) + totals + class parameters.  One block: each
+// thread owns a run of consecutive blocks for all 7 categories at once, the 256 run sums are scanned
+// with wave shuffles + one LDS hop.
 __global__ __launch_bounds__(kBlock) void route_totals_kernel(int32_t *__restrict__ blockcnt, int nblocks,
                                                               int32_t *__restrict__ counts, ClassParams *__restrict__ params) {
+    __shared__ int wsum[kBlock / 64][8];
     __shared__ int tot[8];
-    __shared__ int part[kBlock];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (nblocks + kBlock - 1) / kBlock;
-    const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
-    for (int k = 0; k < 7; ++k) {
-        int sum = 0;
-        for (int b = b0; b < b1; ++b) sum += blockcnt[b * 8 + k];
-        part[threadIdx.x] = sum;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int run = 0;
-            for (int t = 0; t < kBlock; ++t) {
-                const int v = part[t];
-                part[t] = run;
-                run += v;
-            }
-            tot[k] = run;
-            counts[k] = run;
-        }
-        __syncthreads();
-        int run = part[threadIdx.x];
-        for (int b = b0; b < b1; ++b) {
-            const int v = blockcnt[b * 8 + k];
-            blockcnt[b * 8 + k] = run;
-            run += v;
-        }
-        __syncthreads();
+    const int b0 = min(nblocks, tid * per), b1 = min(nblocks, b0 + per);
+    int sum[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sum[k] = 0;
+    for (int b = b0; b < b1; ++b) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sum[k] += blockcnt[b * 8 + k];
     }
-    const int k = threadIdx.x;
-    if (k == 0) {
+    int incl[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        int v = sum[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(v, o);
+            if (lane >= o) v += t;
+        }
+        incl[k] = v;
+        if (lane == 63) wsum[wave][k] = v;
+    }
+    __syncthreads();
+    int run[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            if (w < wave) base += wsum[w][k];
+            total += wsum[w][k];
+        }
+        run[k] = base + incl[k] - sum[k];
+        if (tid == 0) { tot[k] = total; counts[k] = total; }
+    }
+    for (int b = b0; b < b1; ++b) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int v = blockcnt[b * 8 + k];
+            blockcnt[b * 8 + k] = run[k];
+            run[k] += v;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
         int start = 0;
         for (int c = 0; c < kNumFgClasses; ++c) {
             ClassParams p;
@@ -161,17 +180,6 @@ __global__ __launch_bounds__(kBlock) void route_scatter_kernel(CloudView in, con
     }
 }
 
-__global__ __launch_bounds__(kBlock) void stat_init_kernel(ClusterStat *__restrict__ stat, int n) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    ClusterStat s;
-    s.lo[0] = s.lo[1] = s.lo[2] = ~0ull;
-    s.hi[0] = s.hi[1] = s.hi[2] = 0ull;
-    s.count = 0;
-    s.first = INT_MAX;
-    stat[i] = s;
-}
-
 struct ClusterConsts {
     double dA, dR, dP;
     double min_az;  // -24.8 deg in rad, computed on the host exactly as the reference writes it
@@ -196,30 +204,77 @@ __device__ inline int find_root(const int32_t *parent, int v) {
 
 __device__ inline uint32_t cell_hash(int key) { return (uint32_t)key * 2654435761u; }
 
-// one workgroup per class
-__global__ __launch_bounds__(kBlock) void cluster_class_kernel(CloudView in, ClassParams *__restrict__ params,
-                                                               const int32_t *__restrict__ fg_order, ClusterConsts K,
-                                                               int32_t *__restrict__ cell3, int32_t *__restrict__ cellslot,
-                                                               int32_t *__restrict__ cell_pts, CellSlot *__restrict__ table_all,
-                                                               int32_t *label_all, int32_t *parent_all) {
-    const int c = blockIdx.x;
-    const int n = params[c].n;
-    if (n <= 0) return;
-    const int start = params[c].start;
+__device__ inline unsigned long long enc_double(double d) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __host__ inline double dec_double(unsigned long long e) {
+    const unsigned long long b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
+    double d;
+    memcpy(&d, &b, sizeof(d));
+    return d;
+}
+
+// memory traffic between lanes of ONE wavefront (the greedy walk runs on wave 0 alone while the other
+// waves wait at the block barrier behind it, so it must not use the block barrier itself)
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// block-wide exclusive scan of one int per thread (kBlock threads); returns the exclusive prefix, *total = sum
+__device__ inline int block_excl_scan(int v, int *wsum /*shared [kBlock/64]*/, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();  // wsum may still be read from a previous call
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        if (w < wave) base += wsum[w];
+        tot += wsum[w];
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// Per-class working set of the clustering.  All of it is touched by the serial greedy walk, one
+// dependent access after another, so it lives in LDS whenever the class fits (a global round trip
+// is ~10x an LDS one): label n, parent n+1, cell coordinates 3n, cell point lists n, cell table
+// 3 x cap words.  Classes too large for that run the same code on global scratch.
+constexpr int kLdsWords = 36 * 1024;  // 144 KiB of the CU's 160 KiB
+struct ClusterMem {
+    int32_t *label;   // [n] cluster label per point (class order), -1 = none yet
+    int32_t *parent;  // [n+1] union-find over label values; [1..n] doubles as the point->slot map while building
+    int32_t *c3;      // [3n] polar, range, azimuth cell coordinates
+    int32_t *cpts;    // [n] point lists of the cells, concatenated
+    int32_t *tkey, *tend, *tcount;  // [cap] cell table: voxel_index / INT_MIN, END of the point list, points
+    int tmask;
+};
+
+template <bool LDS>
+__device__ __forceinline__ void cluster_class_body(const int c, const int n, const CloudView in, ClassParams *params,
+                                                   const int32_t *__restrict__ order, const ClusterConsts K,
+                                                   const ClusterMem M, ClusterStat *stat_out /*global, [v], v = 1..*/,
+                                                   ClusterStat *stat_lds, const int stat_lds_cap,
+                                                   int32_t *__restrict__ pt_cluster) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t *order = fg_order + start;
-    int32_t *label = label_all + start;
-    int32_t *parent = parent_all + start + c;  // indexed by label value 1..n
-    int32_t *cpts = cell_pts + start;
-    int32_t *c3 = cell3 + 4 * (size_t)start;
-    int32_t *cslot = cellslot + start;
-    CellSlot *table = table_all + params[c].table_off;
-    const int tmask = params[c].table_mask;
+    int32_t *const label = M.label, *const parent = M.parent, *const c3 = M.c3, *const cpts = M.cpts;
+    int32_t *const tkey = M.tkey, *const tend = M.tend, *const tcount = M.tcount;
+    int32_t *const cslot = parent + 1;
+    const int tmask = M.tmask;
 
     __shared__ double s_min[kBlock / 64], s_max[kBlock / 64];
-    __shared__ double s_minR, s_maxR;
-    __shared__ int s_len;
-    __shared__ int s_scan[kBlock];
+    __shared__ double s_minR;
+    __shared__ int s_len, s_current;
+    __shared__ int s_wsum[kBlock / 64];
     __shared__ int s_excl[28], s_cstart[27];
 
     // ---- A: calculateAPR range extrema (:22-36)
@@ -238,6 +293,7 @@ __global__ __launch_bounds__(kBlock) void cluster_class_kernel(CloudView in, Cla
         mx = b > mx ? b : mx;
     }
     if (lane == 0) { s_min[wave] = mn; s_max[wave] = mx; }
+    for (int s = tid; s <= tmask; s += kBlock) { tkey[s] = INT_MIN; tcount[s] = 0; }
     __syncthreads();
     if (tid == 0) {
         double a = s_min[0], b = s_max[0];
@@ -245,12 +301,11 @@ __global__ __launch_bounds__(kBlock) void cluster_class_kernel(CloudView in, Cla
             a = s_min[w] < a ? s_min[w] : a;
             b = s_max[w] > b ? s_max[w] : b;
         }
-        s_minR = a; s_maxR = b;
+        s_minR = a;
         s_len = (int)((b - a) / K.dR) + 1;  // :37
         params[c].min_range = a; params[c].max_range = b;
         params[c].length = s_len; params[c].width = K.width; params[c].height = K.height;
     }
-    for (int s = tid; s <= tmask; s += kBlock) table[s] = CellSlot{INT_MIN, 0, 0, 0};
     __syncthreads();
     const double minR = s_minR;
     const int length = s_len, width = K.width, height = K.height;
@@ -266,52 +321,38 @@ __global__ __launch_bounds__(kBlock) void cluster_class_kernel(CloudView in, Cla
         const int pol = (int)(polar * 180 / M_PI / K.dP);
         const int rng = (int)((range - minR) / K.dR);
         const int vidx = (pol * length + rng) + azi * length * width;
-        c3[4 * j] = pol; c3[4 * j + 1] = rng; c3[4 * j + 2] = azi; c3[4 * j + 3] = vidx;
+        c3[3 * j] = pol; c3[3 * j + 1] = rng; c3[3 * j + 2] = azi;
         uint32_t s = cell_hash(vidx) & (uint32_t)tmask;
         while (true) {
-            const int cur = atomicCAS(&table[s].key, INT_MIN, vidx);
+            const int cur = atomicCAS(&tkey[s], INT_MIN, vidx);
             if (cur == INT_MIN || cur == vidx) break;
             s = (s + 1u) & (uint32_t)tmask;
         }
-        atomicAdd(&table[s].count, 1);
+        atomicAdd(&tcount[s], 1);
         cslot[j] = (int)s;
         label[j] = -1;
     }
     __syncthreads();
 
-    // ---- C: exclusive scan of the cell counts -> list starts
+    // ---- C: exclusive scan of the cell counts -> list starts (kept in tend, advanced to the ends by D)
     const int cap = tmask + 1;
     const int per = (cap + kBlock - 1) / kBlock;
     {
         int sum = 0;
-        for (int s = tid * per; s < (tid + 1) * per && s < cap; ++s) sum += table[s].count;
-        s_scan[tid] = sum;
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int t = 0; t < kBlock; ++t) {
-                const int v = s_scan[t];
-                s_scan[t] = run;
-                run += v;
-            }
-        }
-        __syncthreads();
-        int run = s_scan[tid];
+        for (int s = tid * per; s < (tid + 1) * per && s < cap; ++s) sum += tcount[s];
+        int total;
+        int run = block_excl_scan(sum, s_wsum, &total);
         for (int s = tid * per; s < (tid + 1) * per && s < cap; ++s) {
-            table[s].start = run;
-            run += table[s].count;
+            tend[s] = run;
+            run += tcount[s];
         }
     }
     __syncthreads();
     // ---- D: fill the per-cell lists, then sort each by point index (insertion order of :58)
-    for (int j = tid; j < n; j += kBlock) {
-        const int s = cslot[j];
-        const int pos = table[s].start + atomicAdd(&table[s].cursor, 1);
-        cpts[pos] = j;
-    }
+    for (int j = tid; j < n; j += kBlock) cpts[atomicAdd(&tend[cslot[j]], 1)] = j;
     __syncthreads();
     for (int s = tid; s < cap; s += kBlock) {
-        const int cnt = table[s].count, st = table[s].start;
+        const int cnt = tcount[s], st = tend[s] - cnt;
         for (int a = 1; a < cnt; ++a) {
             const int v = cpts[st + a];
             int b = a - 1;
@@ -323,146 +364,256 @@ __global__ __launch_bounds__(kBlock) void cluster_class_kernel(CloudView in, Cla
         }
     }
     __syncthreads();
-    if (tid >= 64) return;
 
-    // ---- F: the greedy labelling (:109-174), seeds in input order, one wavefront
-    int current = 0;
-    for (int base = 0; base < n; base += 64) {
-        while (true) {
-            const int jj = base + lane;
-            const int lab = jj < n ? label[jj] : 0;
-            const unsigned long long um = __ballot(jj < n && lab == -1);
-            if (!um) break;
-            const int i = base + __ffsll((long long)um) - 1;  // next unlabelled point = seed
-            const int pol = c3[4 * i], rng = c3[4 * i + 1], azi = c3[4 * i + 2];
-            // neighbour cells in z / y / x order (find_neighbors :72-99)
-            int ccount = 0, cstart = 0;
-            if (lane < 27) {
-                const int z = azi + lane / 9 - 1, y = rng + (lane / 3) % 3 - 1, x = pol + lane % 3 - 1;
-                if (!(z < 0 || z > height - 1) && !(y < 0 || y > length - 1)) {
-                    int px = x;
-                    if (x < 0) px = width - 1;
-                    if (x > width - 1) px = 0;
-                    const int key = (px * length + y) + z * length * width;
-                    uint32_t s = cell_hash(key) & (uint32_t)tmask;
-                    for (int step = 0; step <= tmask; ++step) {
-                        const CellSlot e = table[s];
-                        if (e.key == key) { ccount = e.count; cstart = e.start; break; }
-                        if (e.key == INT_MIN) break;
-                        s = (s + 1u) & (uint32_t)tmask;
+    // ---- F: the greedy labelling (:109-174), seeds in input order, wave 0 alone
+    if (wave == 0) {
+        int current = 0;
+        for (int base = 0; base < n; base += 64) {
+            while (true) {
+                const int jj = base + lane;
+                const int lab = jj < n ? label[jj] : 0;
+                const unsigned long long um = __ballot(jj < n && lab == -1);
+                if (!um) break;
+                const int i = base + __ffsll((long long)um) - 1;  // next unlabelled point = seed
+                const int pol = c3[3 * i], rng = c3[3 * i + 1], azi = c3[3 * i + 2];
+                // neighbour cells in z / y / x order (find_neighbors :72-99)
+                int ccount = 0, cstart = 0;
+                if (lane < 27) {
+                    const int z = azi + lane / 9 - 1, y = rng + (lane / 3) % 3 - 1, x = pol + lane % 3 - 1;
+                    if (!(z < 0 || z > height - 1) && !(y < 0 || y > length - 1)) {
+                        int px = x;
+                        if (x < 0) px = width - 1;
+                        if (x > width - 1) px = 0;
+                        const int key = (px * length + y) + z * length * width;
+                        uint32_t s = cell_hash(key) & (uint32_t)tmask;
+                        for (int step = 0; step <= tmask; ++step) {
+                            const int k = tkey[s];
+                            if (k == key) { ccount = tcount[s]; cstart = tend[s] - ccount; break; }
+                            if (k == INT_MIN) break;
+                            s = (s + 1u) & (uint32_t)tmask;
+                        }
                     }
                 }
-            }
-            int incl = ccount;
+                int incl = ccount;
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                const int up = __shfl_up(incl, o);
-                if (lane >= o) incl += up;
-            }
-            const int m = __shfl(incl, 26);
-            if (lane < 27) { s_excl[lane] = incl - ccount; s_cstart[lane] = cstart; }
-            if (lane == 27) s_excl[27] = m;
-            __syncthreads();
-            int oc = -1;
-            for (int t0 = 0; t0 < m; t0 += 64) {
-                const int t = t0 + lane;
-                const bool valid = t < m;
-                int nj = -1, root = -1;
-                if (valid) {
-                    int k = 0;
-#pragma unroll
-                    for (int step = 16; step > 0; step >>= 1)
-                        if (k + step < 27 && s_excl[k + step] <= t) k += step;
-                    nj = cpts[s_cstart[k] + (t - s_excl[k])];
-                    const int lj = label[nj];
-                    if (lj > 0) root = find_root(parent, lj);
+                for (int o = 1; o < 32; o <<= 1) {
+                    const int up = __shfl_up(incl, o);
+                    if (lane >= o) incl += up;
                 }
-                unsigned long long active = __ballot(valid);
-                if (oc == -1) {
-                    const unsigned long long labelled = __ballot(valid && root != -1);
-                    if (!labelled) continue;  // everything here precedes the first labelled neighbour
-                    const int fl = __ffsll((long long)labelled) - 1;
-                    oc = __shfl(root, fl);
-                    active &= ~((2ull << fl) - 1ull);  // positions after the first labelled one
-                }
-                const bool mine = (active >> lane) & 1ull;
-                while (true) {
-                    const unsigned long long diff = __ballot(mine && root != -1 && root != oc);
-                    if (!diff) break;
-                    const int dl = __ffsll((long long)diff) - 1;
-                    const int nc = __shfl(root, dl);
-                    if (lane == 0) parent[oc] = nc;  // mergeClusters(oc -> nc)
-                    if (root == oc) root = nc;
-                    oc = nc;
-                }
-                if (mine && root == -1) label[nj] = oc;
-                __syncthreads();
-            }
-            if (oc == -1) {  // nobody around was labelled: new cluster for the seed and all neighbours
-                ++current;
-                if (lane == 0) { parent[current] = current; label[i] = current; }
+                const int m = __shfl(incl, 26);
+                if (lane < 27) { s_excl[lane] = incl - ccount; s_cstart[lane] = cstart; }
+                if (lane == 27) s_excl[27] = m;
+                wave_sync();
+                int oc = -1;
                 for (int t0 = 0; t0 < m; t0 += 64) {
                     const int t = t0 + lane;
-                    if (t < m) {
+                    const bool valid = t < m;
+                    int nj = -1, root = -1;
+                    if (valid) {
                         int k = 0;
 #pragma unroll
                         for (int step = 16; step > 0; step >>= 1)
                             if (k + step < 27 && s_excl[k + step] <= t) k += step;
-                        label[cpts[s_cstart[k] + (t - s_excl[k])]] = current;
+                        nj = cpts[s_cstart[k] + (t - s_excl[k])];
+                        const int lj = label[nj];
+                        if (lj > 0) root = find_root(parent, lj);
                     }
+                    unsigned long long active = __ballot(valid);
+                    if (oc == -1) {
+                        const unsigned long long labelled = __ballot(valid && root != -1);
+                        if (!labelled) continue;  // everything here precedes the first labelled neighbour
+                        const int fl = __ffsll((long long)labelled) - 1;
+                        oc = __shfl(root, fl);
+                        active &= ~((2ull << fl) - 1ull);  // positions after the first labelled one
+                    }
+                    const bool mine = (active >> lane) & 1ull;
+                    while (true) {
+                        const unsigned long long diff = __ballot(mine && root != -1 && root != oc);
+                        if (!diff) break;
+                        const int dl = __ffsll((long long)diff) - 1;
+                        const int nc = __shfl(root, dl);
+                        if (lane == 0) parent[oc] = nc;  // mergeClusters(oc -> nc)
+                        if (root == oc) root = nc;
+                        oc = nc;
+                    }
+                    if (mine && root == -1) label[nj] = oc;
+                    wave_sync();
                 }
-            } else if (lane == 0) {
-                label[i] = oc;
+                if (oc == -1) {  // nobody around was labelled: new cluster for the seed and all neighbours
+                    ++current;
+                    if (lane == 0) { parent[current] = current; label[i] = current; }
+                    for (int t0 = 0; t0 < m; t0 += 64) {
+                        const int t = t0 + lane;
+                        if (t < m) {
+                            int k = 0;
+#pragma unroll
+                            for (int step = 16; step > 0; step >>= 1)
+                                if (k + step < 27 && s_excl[k + step] <= t) k += step;
+                            label[cpts[s_cstart[k] + (t - s_excl[k])]] = current;
+                        }
+                    }
+                } else if (lane == 0) {
+                    label[i] = oc;
+                }
+                wave_sync();
             }
-            __syncthreads();
+        }
+        if (lane == 0) {
+            params[c].n_labels = current;
+            s_current = current;
         }
     }
-    if (lane == 0) params[c].n_labels = current;
+    __syncthreads();
+
+    // ---- G: per-cluster count / first index / AABB (:278-304), final label of every point.  The
+    // accumulators sit in LDS (the cell table's words, free now) unless there are too many clusters.
+    const int current = s_current;
+    ClusterStat *const acc = (LDS && current <= stat_lds_cap) ? stat_lds : stat_out;  // generic pointer: flat atomics
+    for (int v = 1 + tid; v <= current; v += kBlock) {
+        ClusterStat e;
+        e.lo[0] = e.lo[1] = e.lo[2] = ~0ull;
+        e.hi[0] = e.hi[1] = e.hi[2] = 0ull;
+        e.count = 0;
+        e.first = INT_MAX;
+        acc[v] = e;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += kBlock) {
+        const int v = find_root(parent, label[j]);
+        const int oi = order[j];
+        pt_cluster[oi] = v;
+        ClusterStat *e = acc + v;
+        atomicAdd(&e->count, 1);
+        atomicMin(&e->first, j);
+        const unsigned long long ex = enc_double(in.x[oi]), ey = enc_double(in.y[oi]), ez = enc_double(in.z[oi]);
+        atomicMin(&e->lo[0], ex); atomicMax(&e->hi[0], ex);
+        atomicMin(&e->lo[1], ey); atomicMax(&e->hi[1], ey);
+        atomicMin(&e->lo[2], ez); atomicMax(&e->hi[2], ez);
+    }
+    if (acc != stat_out) {
+        __syncthreads();
+        for (int v = 1 + tid; v <= current; v += kBlock) stat_out[v] = acc[v];
+    }
 }
 
-__device__ inline unsigned long long enc_double(double d) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-inline double dec_double(unsigned long long e) {
-    const unsigned long long b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
-    double d;
-    memcpy(&d, &b, sizeof(d));
-    return d;
-}
-
-__global__ __launch_bounds__(kBlock) void cluster_stats_kernel(CloudView in, const ClassParams *__restrict__ params,
-                                                               const int32_t *__restrict__ counts,
-                                                               const int32_t *__restrict__ fg_order,
-                                                               const int32_t *__restrict__ label_all,
-                                                               const int32_t *__restrict__ parent_all,
-                                                               ClusterStat *__restrict__ stat, int32_t *__restrict__ pt_cluster) {
-    const int g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= counts[5]) return;
-    int c = 0;
-#pragma unroll
-    for (int k = 1; k < kNumFgClasses; ++k)
-        if (g >= params[k].start) c = k;
+// one workgroup per class
+__global__ __launch_bounds__(kBlock) void cluster_class_kernel(CloudView in, ClassParams *params,
+                                                               const int32_t *__restrict__ fg_order, ClusterConsts K,
+                                                               int32_t *cell3, int32_t *cell_pts, int32_t *table_all,
+                                                               int32_t *label_all, int32_t *parent_all, ClusterStat *stat,
+                                                               int32_t *__restrict__ pt_cluster) {
+    __shared__ __align__(16) int32_t smem[kLdsWords];
+    const int c = blockIdx.x;
+    const int n = params[c].n;
+    if (n <= 0) return;
     const int start = params[c].start;
-    const int j = g - start;
-    const int v = find_root(parent_all + start + c, label_all[g]);
-    const int oi = fg_order[g];
-    pt_cluster[oi] = v;
-    ClusterStat *s = stat + start + c + v;
-    atomicAdd(&s->count, 1);
-    atomicMin(&s->first, j);
-    const unsigned long long ex = enc_double(in.x[oi]), ey = enc_double(in.y[oi]), ez = enc_double(in.z[oi]);
-    atomicMin(&s->lo[0], ex); atomicMax(&s->hi[0], ex);
-    atomicMin(&s->lo[1], ey); atomicMax(&s->hi[1], ey);
-    atomicMin(&s->lo[2], ez); atomicMax(&s->hi[2], ez);
+    ClusterStat *stat_out = stat + start + c;  // indexed by label value 1..n
+    int cap = 1;
+    while (cap < n + n / 2 + 1) cap <<= 1;
+    if (6 * n + 4 + 3 * cap <= kLdsWords) {
+        ClusterMem M;
+        M.label = smem;
+        M.parent = smem + n;
+        M.c3 = smem + 2 * n + 1;
+        M.cpts = smem + 5 * n + 1;
+        int32_t *tab = smem + 6 * n + 1;
+        tab += (4 - ((6 * n + 1) & 3)) & 3;  // 16-byte aligned: the words double as ClusterStat records later
+        M.tkey = tab; M.tend = tab + cap; M.tcount = tab + 2 * cap;
+        M.tmask = cap - 1;
+        const int room = (int)(smem + kLdsWords - tab);  // >= 3 * cap - 3
+        cluster_class_body<true>(c, n, in, params, fg_order + start, K, M, stat_out, reinterpret_cast<ClusterStat *>(tab),
+                                 room / 16 - 1, pt_cluster);
+    } else {
+        ClusterMem M;
+        M.label = label_all + start;
+        M.parent = parent_all + start + c;
+        M.c3 = cell3 + 4 * (size_t)start;
+        M.cpts = cell_pts + start;
+        const int gcap = params[c].table_mask + 1;  // pow2 >= 2n, slice of 16n words
+        int32_t *tab = table_all + 16 * (size_t)start;
+        M.tkey = tab; M.tend = tab + gcap; M.tcount = tab + 2 * (size_t)gcap;
+        M.tmask = gcap - 1;
+        cluster_class_body<false>(c, n, in, params, fg_order + start, K, M, stat_out, nullptr, 0, pt_cluster);
+    }
 }
 
-// ---- BuildGraph edges + histogram (F/SemGraph.cpp:24-62): one block per node row ----
-__global__ __launch_bounds__(128) void graph_edges_kernel(const double *__restrict__ boxes, int nb, double edge_dis_th,
-                                                          int sub_interval_value, int subinterval,
+// ---- boxes: keep the clusters with >= 10 points and a large enough AABB (:305-353), in (class, label)
+// order; every non-empty cluster is also listed for the host, which needs them all to replay the
+// reference's unordered_map iteration order.  Results go straight to host-mapped memory.
+struct ClusterRec {
+    int32_t cls, label, first, box;  // box = index in the device-order box list, -1 = filtered out
+};
+struct GraphHostHeader {
+    int32_t counts[8];                  // per class n (5), n_fg, n_bg
+    ClassParams params[kNumFgClasses];
+    int32_t n_clusters, n_boxes, pad[2];
+};
+
+__global__ __launch_bounds__(kBlock) void cluster_boxes_kernel(const ClassParams *__restrict__ params,
+                                                               const int32_t *__restrict__ counts,
+                                                               const ClusterStat *__restrict__ stat,
+                                                               GraphHostHeader *hdr, ClusterRec *recs, int rec_cap,
+                                                               double *boxes_host, double *boxes_dev, int box_cap,
+                                                               int node_cap, int32_t *n_boxes_dev) {
+    __shared__ int s_wsum[kBlock / 64];
+    const int tid = threadIdx.x;
+    int rec_base = 0, box_base = 0;
+    for (int c = 0; c < kNumFgClasses; ++c) {
+        const ClassParams p = params[c];
+        if (tid == 0) hdr->params[c] = p;
+        if (p.n <= 0 || p.n_labels <= 0) continue;
+        const ClusterStat *st = stat + p.start + c;
+        const int lab = c < 3 ? 1 : (c == 3 ? 2 : 3);  // :311-322
+        for (int v0 = 1; v0 <= p.n_labels; v0 += kBlock) {
+            const int v = v0 + tid;
+            bool nonempty = false, keep = false;
+            ClusterStat q{};
+            double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, dim[3] = {0, 0, 0};
+            if (v <= p.n_labels) {
+                q = st[v];
+                nonempty = q.count > 0;
+                if (q.count >= 10) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { lo[a] = dec_double(q.lo[a]); hi[a] = dec_double(q.hi[a]); dim[a] = hi[a] - lo[a]; }
+                    keep = lab == 1 ? !(dim[0] < 0.5 || dim[1] < 0.5 || dim[2] < 0.3) : !(dim[2] < 0.3);
+                }
+            }
+            int nrec, nbox;
+            const int rpos = rec_base + block_excl_scan(nonempty ? 1 : 0, s_wsum, &nrec);
+            const int bpos = box_base + block_excl_scan(keep ? 1 : 0, s_wsum, &nbox);
+            if (nonempty && rpos < rec_cap) recs[rpos] = ClusterRec{c, v, q.first, keep ? bpos : -1};
+            if (keep && bpos < box_cap) {
+                const double b[8] = {(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2, dim[0], dim[1], dim[2],
+                                     (double)lab, (double)q.count};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    boxes_host[8 * (size_t)bpos + k] = b[k];
+                    boxes_dev[8 * (size_t)bpos + k] = b[k];
+                }
+            }
+            rec_base += nrec;
+            box_base += nbox;
+        }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hdr->counts[k] = counts[k];
+        hdr->n_clusters = rec_base;
+        hdr->n_boxes = box_base;
+        *n_boxes_dev = box_base <= node_cap ? box_base : 0;  // over capacity: no graph, the host reports it
+    }
+}
+
+// ---- BuildGraph edges + histogram (F/SemGraph.cpp:24-62): one block per node row.  The node count
+// comes from device memory when nb_ptr is given (pipeline: the host does not know it yet); rows past
+// it exit.  Row/column order is whatever order `boxes` is in: the host permutes to the reference's.
+__global__ __launch_bounds__(128) void graph_edges_kernel(const double *__restrict__ boxes, const int32_t *nb_ptr, int nb_arg,
+                                                          double edge_dis_th, int sub_interval_value, int subinterval,
                                                           double *__restrict__ edge, int32_t *__restrict__ hist) {
     extern __shared__ int s_hist[];
+    const int nb = nb_ptr ? *nb_ptr : nb_arg;
     const int i = blockIdx.x;
+    if (i >= nb) return;
     const int cols = 3 * subinterval;
     for (int k = threadIdx.x; k < cols; k += blockDim.x) s_hist[k] = 0;
     __syncthreads();
@@ -602,40 +753,66 @@ int gfail(std::string *err, int code, const char *msg) {
 
 }  // namespace
 
+// layout of the host-mapped result block the cluster / graph kernels write into
+constexpr size_t kHbRecs = 1024;
+constexpr size_t kHbBoxes = kHbRecs + sizeof(ClusterRec) * (size_t)kMaxClusters;
+constexpr size_t kHbEdge = kHbBoxes + sizeof(double) * 8 * (size_t)kMaxClusters;
+constexpr size_t kHbHist = kHbEdge + sizeof(double) * (size_t)kMaxNodes * kMaxNodes;
+constexpr size_t kHbBytes = kHbHist + sizeof(int32_t) * (size_t)kMaxNodes * kMaxHistCols;
+static_assert(sizeof(GraphHostHeader) <= kHbRecs, "header must fit in front of the records");
+
 int graph_scratch_alloc(GraphScratch &g, int N) {
     g.N = N;
     const size_t n = (size_t)N;
     bool ok = galloc(&g.cat_blockcnt, (n / kBlock + 2) * 8) && galloc(&g.fg_order, n) && galloc(&g.fg_all, n) &&
               galloc(&g.bg_all, n) && galloc(&g.counts, 8) && galloc(&g.params, kNumFgClasses) && galloc(&g.cell3, n * 4) &&
-              galloc(&g.cellslot, n) && galloc(&g.cell_pts, n) && galloc(&g.table, n * 4 + 16) && galloc(&g.label, n) &&
+              galloc(&g.cell_pts, n) && galloc(&g.table, n * 4 + 16) && galloc(&g.label, n) &&
               galloc(&g.parent, n + 16) && galloc(&g.stat, n + 16) && galloc(&g.pt_cluster, n) &&
-              galloc(&g.boxes_dev, (size_t)kMaxNodes * 8) && galloc(&g.edge_dev, (size_t)kMaxNodes * kMaxNodes) &&
-              galloc(&g.hist_dev, (size_t)kMaxNodes * kMaxHistCols);
-    if (ok) ok = hipHostMalloc((void **)&g.pinned, 1024, hipHostMallocDefault) == hipSuccess;
+              galloc(&g.boxes_dev, (size_t)kMaxClusters * 8) && galloc(&g.edge_dev, (size_t)kMaxNodes * kMaxNodes) &&
+              galloc(&g.hist_dev, (size_t)kMaxNodes * kMaxHistCols) && galloc(&g.n_boxes_dev, 4);
+    if (ok) ok = hipHostMalloc((void **)&g.hostblk, kHbBytes, hipHostMallocMapped) == hipSuccess &&
+                 hipHostGetDevicePointer((void **)&g.hostblk_dev, g.hostblk, 0) == hipSuccess;
+    if (ok) memset(g.hostblk, 0, kHbRecs);
     return ok ? SGS_OK : SGS_ENOMEM;
 }
 
 void graph_scratch_free(GraphScratch &g) {
-    void *ps[] = {g.cat_blockcnt, g.fg_order, g.fg_all, g.bg_all, g.counts, g.params, g.cell3, g.cellslot, g.cell_pts,
-                  g.table, g.label, g.parent, g.stat, g.pt_cluster, g.boxes_dev, g.edge_dev, g.hist_dev};
+    void *ps[] = {g.cat_blockcnt, g.fg_order, g.fg_all, g.bg_all, g.counts, g.params, g.cell3, g.cell_pts,
+                  g.table, g.label, g.parent, g.stat, g.pt_cluster, g.boxes_dev, g.edge_dev, g.hist_dev, g.n_boxes_dev};
     for (void *p : ps)
         if (p) hipFree(p);
-    if (g.pinned) hipHostFree(g.pinned);
+    if (g.hostblk) hipHostFree(g.hostblk);
     g = GraphScratch();
 }
 
-// All cluster kernels + the small async read-back of counts / class parameters; no host sync.
+namespace {
+int graph_params_check(double edge_dis_th, int subinterval, int dim, int *sub_interval_value, std::string *err) {
+    if (subinterval < 1 || 3 * subinterval > kMaxHistCols || dim < 0) return gfail(err, SGS_EINVAL, "bad graph parameters");
+    *sub_interval_value = int(edge_dis_th / subinterval);  // F/SemGraph.cpp:16 (integer!)
+    if (*sub_interval_value < 1) return gfail(err, SGS_EINVAL, "edge_dis_th / subinterval truncates to 0");
+    return SGS_OK;
+}
+}  // namespace
+
+// Every cluster kernel and, with with_graph, the edge / histogram kernel on the boxes in device order:
+// one dependent chain on the stream, results written by the kernels into host-mapped memory, no copy
+// and no host sync in between.
 int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper,
-                          const sgs_config &cfg, std::string *err) {
+                          const sgs_config &cfg, bool with_graph, std::string *err) {
     g.enqueued_upper = n_upper;
+    g.enqueued_graph = false;
     if (n_upper <= 0) return SGS_OK;
     if (!(cfg.deltaA > 0) || !(cfg.deltaR > 0) || !(cfg.deltaP > 0)) return gfail(err, SGS_EINVAL, "cluster deltas must be positive");
+    int sub_interval_value = 0;
+    if (with_graph) {
+        const int r = graph_params_check(cfg.edge_dis_th, cfg.subinterval, cfg.graph_node_dimension, &sub_interval_value, err);
+        if (r) return r;
+    }
     const int nb = (n_upper + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(route_count_kernel, dim3(nb), dim3(kBlock), 0, s, in, n_ptr, g.cat_blockcnt, g.pt_cluster);
     hipLaunchKernelGGL(route_totals_kernel, dim3(1), dim3(kBlock), 0, s, g.cat_blockcnt, nb, g.counts, g.params);
     hipLaunchKernelGGL(route_scatter_kernel, dim3(nb), dim3(kBlock), 0, s, in, n_ptr, g.cat_blockcnt, g.params, g.fg_order,
                        g.fg_all, g.bg_all);
-    hipLaunchKernelGGL(stat_init_kernel, dim3((n_upper + 16 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g.stat, n_upper + 16);
     ClusterConsts K;
     K.dA = cfg.deltaA; K.dR = cfg.deltaR; K.dP = cfg.deltaP;
     // F/SemanticCluster.hpp:46-47 and .cpp:38-39, evaluated on the host in the reference's expression order
@@ -644,68 +821,60 @@ int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const in
     K.width = int(round(360 / cfg.deltaP));
     K.height = int(((max_az - min_az) * 180 / M_PI) / cfg.deltaA) + 1;
     hipLaunchKernelGGL(cluster_class_kernel, dim3(kNumFgClasses), dim3(kBlock), 0, s, in, g.params, g.fg_order, K, g.cell3,
-                       g.cellslot, g.cell_pts, g.table, g.label, g.parent);
-    hipLaunchKernelGGL(cluster_stats_kernel, dim3(nb), dim3(kBlock), 0, s, in, g.params, g.counts, g.fg_order, g.label,
-                       g.parent, g.stat, g.pt_cluster);
-    // counts (8 ints) and params (5 structs) land in one pinned block
-    if (hipMemcpyAsync(g.pinned, g.counts, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipMemcpyAsync(g.pinned + 64, g.params, sizeof(ClassParams) * kNumFgClasses, hipMemcpyDeviceToHost, s) != hipSuccess)
-        return gfail(err, SGS_EHIP, "cluster: device error");
+                       g.cell_pts, reinterpret_cast<int32_t *>(g.table), g.label, g.parent, g.stat, g.pt_cluster);
+    char *hb = g.hostblk_dev;
+    hipLaunchKernelGGL(cluster_boxes_kernel, dim3(1), dim3(kBlock), 0, s, g.params, g.counts, g.stat,
+                       reinterpret_cast<GraphHostHeader *>(hb), reinterpret_cast<ClusterRec *>(hb + kHbRecs), kMaxClusters,
+                       reinterpret_cast<double *>(hb + kHbBoxes), g.boxes_dev, kMaxClusters, kMaxNodes, g.n_boxes_dev);
+    if (with_graph) {
+        hipLaunchKernelGGL(graph_edges_kernel, dim3(kMaxNodes), dim3(128), sizeof(int) * 3 * (size_t)cfg.subinterval, s,
+                           g.boxes_dev, g.n_boxes_dev, 0, cfg.edge_dis_th, sub_interval_value, cfg.subinterval,
+                           reinterpret_cast<double *>(hb + kHbEdge), reinterpret_cast<int32_t *>(hb + kHbHist));
+        g.enqueued_graph = true;
+    }
+    if (hipGetLastError() != hipSuccess) return gfail(err, SGS_EHIP, "cluster: launch failed");
     return SGS_OK;
 }
 
-// Waits for the cluster kernels, reads the per-cluster statistics back in one copy and emits the boxes
-// in the reference's order.
+// Waits for the cluster kernels and emits the boxes in the reference's order; box_perm (optional)
+// receives, per emitted box, its index in the device-order list the edge kernel worked on.
 int graph_cluster_finish(hipStream_t s, GraphScratch &g, const int32_t *n_ptr, std::vector<double> *boxes, int *n_boxes,
-                         int32_t *point_cluster_host, int *n_fg, int *n_bg, std::string *err) {
+                         int32_t *point_cluster_host, int *n_fg, int *n_bg, std::vector<int> *box_perm, std::string *err) {
     if (boxes) boxes->clear();
+    if (box_perm) box_perm->clear();
     if (n_boxes) *n_boxes = 0;
     if (n_fg) *n_fg = 0;
     if (n_bg) *n_bg = 0;
     if (g.enqueued_upper <= 0) return SGS_OK;
     if (hipStreamSynchronize(s) != hipSuccess) return gfail(err, SGS_EHIP, "cluster: device error");
-    int32_t counts[8];
-    memcpy(counts, g.pinned, sizeof(counts));
-    memcpy(g.params_host, g.pinned + 64, sizeof(ClassParams) * kNumFgClasses);
-    if (n_fg) *n_fg = counts[5];
-    if (n_bg) *n_bg = counts[6];
+    const GraphHostHeader &hdr = *reinterpret_cast<const GraphHostHeader *>(g.hostblk);
+    const ClusterRec *recs = reinterpret_cast<const ClusterRec *>(g.hostblk + kHbRecs);
+    const double *hb_boxes = reinterpret_cast<const double *>(g.hostblk + kHbBoxes);
+    memcpy(g.params_host, hdr.params, sizeof(ClassParams) * kNumFgClasses);
+    if (n_fg) *n_fg = hdr.counts[5];
+    if (n_bg) *n_bg = hdr.counts[6];
+    if (hdr.n_clusters > kMaxClusters) return gfail(err, SGS_ECAPACITY, "more instance clusters than the result block holds");
     int total = 0;
-    static const int kClassLabel[kNumFgClasses] = {1, 1, 1, 2, 3};  // :311-322
-    const size_t nstat = (size_t)counts[5] + kNumFgClasses + 1;
-    std::vector<ClusterStat> &all = g.stat_host;
-    all.resize(nstat);
-    if (counts[5] > 0 && (hipMemcpyAsync(all.data(), g.stat, sizeof(ClusterStat) * nstat, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                          hipStreamSynchronize(s) != hipSuccess))
-        return gfail(err, SGS_EHIP, "cluster: device error");
-    for (int c = 0; c < kNumFgClasses; ++c) {
-        const ClassParams &p = g.params_host[c];
-        if (p.n <= 0 || p.n_labels <= 0) continue;
-        const ClusterStat *st = all.data() + p.start + c + 1;
-        // replay histcounts[...] insertion (:278-304): keys enter in order of first appearance
-        std::vector<int> ids;
-        for (int v = 1; v <= p.n_labels; ++v)
-            if (st[(size_t)v - 1].count > 0) ids.push_back(v);
-        std::sort(ids.begin(), ids.end(), [&](int a, int b) { return st[(size_t)a - 1].first < st[(size_t)b - 1].first; });
+    int r0 = 0;
+    std::vector<int> ids;
+    while (r0 < hdr.n_clusters) {
+        int r1 = r0;
+        while (r1 < hdr.n_clusters && recs[r1].cls == recs[r0].cls) ++r1;
+        // replay histcounts[...] insertion (:278-304): keys enter in order of first appearance; the
+        // boxes come out in std::unordered_map<int,...> iteration order (:305-307)
+        ids.resize((size_t)(r1 - r0));
+        std::iota(ids.begin(), ids.end(), r0);
+        std::sort(ids.begin(), ids.end(), [&](int a, int b) { return recs[a].first < recs[b].first; });
         std::unordered_map<int, int> hist;
-        for (int v : ids) hist[v] = v;
+        for (int k : ids) hist[recs[k].label] = k;
         for (const auto &kv : hist) {
-            const ClusterStat &q = st[(size_t)kv.first - 1];
-            if (q.count < 10) continue;
-            double lo[3], hi[3];
-            for (int a = 0; a < 3; ++a) { lo[a] = dec_double(q.lo[a]); hi[a] = dec_double(q.hi[a]); }
-            const double dim[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
-            const int lab = kClassLabel[c];
-            if (lab == 1) {
-                if (dim[0] < 0.5 || dim[1] < 0.5 || dim[2] < 0.3) continue;
-            } else if (dim[2] < 0.3) {
-                continue;
-            }
-            if (boxes) {
-                const double b[8] = {(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2, dim[0], dim[1], dim[2], (double)lab, (double)q.count};
-                boxes->insert(boxes->end(), b, b + 8);
-            }
+            const int bi = recs[kv.second].box;
+            if (bi < 0) continue;
+            if (boxes) boxes->insert(boxes->end(), hb_boxes + 8 * (size_t)bi, hb_boxes + 8 * (size_t)bi + 8);
+            if (box_perm) box_perm->push_back(bi);
             ++total;
         }
+        r0 = r1;
     }
     if (n_boxes) *n_boxes = total;
     if (point_cluster_host) {
@@ -722,34 +891,19 @@ int graph_cluster_finish(hipStream_t s, GraphScratch &g, const int32_t *n_ptr, s
 int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper, const sgs_config &cfg,
                   std::vector<double> *boxes, int *n_boxes, int32_t *point_cluster_host, int *n_fg, int *n_bg,
                   std::string *err) {
-    int r = graph_cluster_enqueue(s, g, in, n_ptr, n_upper, cfg, err);
+    int r = graph_cluster_enqueue(s, g, in, n_ptr, n_upper, cfg, false, err);
     if (r) return r;
-    return graph_cluster_finish(s, g, n_ptr, boxes, n_boxes, point_cluster_host, n_fg, n_bg, err);
+    return graph_cluster_finish(s, g, n_ptr, boxes, n_boxes, point_cluster_host, n_fg, n_bg, nullptr, err);
 }
 
-int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
-                double subgraph_edge_th, float *desc, double *edge_matrix, double *eigenvalues, int32_t *edges,
-                double *edge_value, double *edge_weights, int edge_cap, int *n_edges, int32_t *tri_counts, double *triangles,
-                int tri_cap, int *n_triangles, int32_t *class_counts3, std::string *err) {
-    if (n_edges) *n_edges = 0;
-    if (n_triangles) *n_triangles = 0;
-    if (class_counts3) class_counts3[0] = class_counts3[1] = class_counts3[2] = 0;
-    if (nb == 0) return SGS_OK;
-    if (nb > kMaxNodes) return gfail(err, SGS_ECAPACITY, "too many graph nodes");
-    if (subinterval < 1 || 3 * subinterval > kMaxHistCols || dim < 0) return gfail(err, SGS_EINVAL, "bad graph parameters");
-    const int sub_interval_value = int(edge_dis_th / subinterval);  // F/SemGraph.cpp:16 (integer!)
-    if (sub_interval_value < 1) return gfail(err, SGS_EINVAL, "edge_dis_th / subinterval truncates to 0");
+namespace {
+// host half of BuildGraph on the edge matrix E (-1 = no edge) and histogram H, both in `boxes` order
+int graph_host_part(const double *boxes, int nb, double edge_dis_th, int subinterval, int dim, double subgraph_edge_th,
+                    std::vector<double> &E, const std::vector<int32_t> &H, float *desc, double *edge_matrix,
+                    double *eigenvalues, int32_t *edges, double *edge_value, double *edge_weights, int edge_cap,
+                    int *n_edges, int32_t *tri_counts, double *triangles, int tri_cap, int *n_triangles,
+                    int32_t *class_counts3, std::string *err) {
     const int cols = 3 * subinterval;
-    if (hipMemcpyAsync(g.boxes_dev, boxes, sizeof(double) * 8 * (size_t)nb, hipMemcpyHostToDevice, s) != hipSuccess)
-        return gfail(err, SGS_EHIP, "graph: upload failed");
-    hipLaunchKernelGGL(graph_edges_kernel, dim3(nb), dim3(128), sizeof(int) * (size_t)cols, s, g.boxes_dev, nb, edge_dis_th,
-                       sub_interval_value, subinterval, g.edge_dev, g.hist_dev);
-    std::vector<double> E((size_t)nb * nb);
-    std::vector<int32_t> H((size_t)nb * cols);
-    if (hipMemcpyAsync(E.data(), g.edge_dev, sizeof(double) * E.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipMemcpyAsync(H.data(), g.hist_dev, sizeof(int32_t) * H.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess)
-        return gfail(err, SGS_EHIP, "graph: device error");
     // adjacency / edge matrix / edge lists (F/SemGraph.cpp:36-47)
     std::vector<double> Adj((size_t)nb * nb, 0.0);
     int ne = 0;
@@ -831,19 +985,66 @@ int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, dou
     if (nt > tri_cap && triangles) return gfail(err, SGS_ECAPACITY, "triangle capacity too small");
     return SGS_OK;
 }
+}  // namespace
 
+// standalone BuildGraph on boxes given by the host (sgs_build_graph)
+int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
+                double subgraph_edge_th, float *desc, double *edge_matrix, double *eigenvalues, int32_t *edges,
+                double *edge_value, double *edge_weights, int edge_cap, int *n_edges, int32_t *tri_counts, double *triangles,
+                int tri_cap, int *n_triangles, int32_t *class_counts3, std::string *err) {
+    if (n_edges) *n_edges = 0;
+    if (n_triangles) *n_triangles = 0;
+    if (class_counts3) class_counts3[0] = class_counts3[1] = class_counts3[2] = 0;
+    if (nb == 0) return SGS_OK;
+    if (nb > kMaxNodes) return gfail(err, SGS_ECAPACITY, "too many graph nodes");
+    int sub_interval_value = 0;
+    const int rc = graph_params_check(edge_dis_th, subinterval, dim, &sub_interval_value, err);
+    if (rc) return rc;
+    const int cols = 3 * subinterval;
+    if (hipMemcpyAsync(g.boxes_dev, boxes, sizeof(double) * 8 * (size_t)nb, hipMemcpyHostToDevice, s) != hipSuccess)
+        return gfail(err, SGS_EHIP, "graph: upload failed");
+    hipLaunchKernelGGL(graph_edges_kernel, dim3(nb), dim3(128), sizeof(int) * (size_t)cols, s, g.boxes_dev, nullptr, nb,
+                       edge_dis_th, sub_interval_value, subinterval, g.edge_dev, g.hist_dev);
+    std::vector<double> E((size_t)nb * nb);
+    std::vector<int32_t> H((size_t)nb * cols);
+    if (hipMemcpyAsync(E.data(), g.edge_dev, sizeof(double) * E.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(H.data(), g.hist_dev, sizeof(int32_t) * H.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return gfail(err, SGS_EHIP, "graph: device error");
+    return graph_host_part(boxes, nb, edge_dis_th, subinterval, dim, subgraph_edge_th, E, H, desc, edge_matrix, eigenvalues,
+                           edges, edge_value, edge_weights, edge_cap, n_edges, tri_counts, triangles, tri_cap, n_triangles,
+                           class_counts3, err);
+}
+
+// pipeline tail: boxes in the reference's order, then the edge matrix / histogram rows the device
+// computed in ITS box order are permuted into that order and the spectral half runs on the host
 int graph_finish_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, const sgs_config &cfg,
                       std::vector<double> *boxes, int *n_boxes, std::string *err) {
     (void)in;
-    int r = graph_cluster_finish(s, g, n_ptr, boxes, n_boxes, nullptr, nullptr, nullptr, err);
+    std::vector<int> &perm = g.box_perm;
+    int r = graph_cluster_finish(s, g, n_ptr, boxes, n_boxes, nullptr, nullptr, nullptr, &perm, err);
     if (r) return r;
     const int nb = *n_boxes;
-    if (nb == 0) return SGS_OK;
+    if (nb == 0 || !g.enqueued_graph) return SGS_OK;
+    if (nb > kMaxNodes) return gfail(err, SGS_ECAPACITY, "too many graph nodes");
+    const GraphHostHeader &hdr = *reinterpret_cast<const GraphHostHeader *>(g.hostblk);
+    const int nd = hdr.n_boxes;  // device-order box count (== nb: every kept box is emitted exactly once)
+    if (nd != nb) return gfail(err, SGS_EHIP, "graph: box count mismatch");
+    const int cols = 3 * cfg.subinterval;
+    const double *Ed = reinterpret_cast<const double *>(g.hostblk + kHbEdge);
+    const int32_t *Hd = reinterpret_cast<const int32_t *>(g.hostblk + kHbHist);
+    std::vector<double> E((size_t)nb * nb);
+    std::vector<int32_t> H((size_t)nb * cols);
+    for (int i = 0; i < nb; ++i) {
+        const size_t pi = (size_t)perm[(size_t)i];
+        for (int j = 0; j < nb; ++j) E[(size_t)i * nb + j] = Ed[pi * nd + (size_t)perm[(size_t)j]];
+        memcpy(&H[(size_t)i * cols], Hd + pi * cols, sizeof(int32_t) * (size_t)cols);
+    }
     g.last_desc.assign((size_t)nb * (3 * cfg.subinterval + cfg.graph_node_dimension), 0.f);
     int ne = 0, nt = 0;
-    return graph_build(s, g, boxes->data(), nb, cfg.edge_dis_th, cfg.subinterval, cfg.graph_node_dimension,
-                       cfg.subgraph_edge_th, g.last_desc.data(), nullptr, nullptr, nullptr, nullptr, nullptr, 0, &ne, nullptr,
-                       nullptr, 0, &nt, nullptr, err);
+    return graph_host_part(boxes->data(), nb, cfg.edge_dis_th, cfg.subinterval, cfg.graph_node_dimension, cfg.subgraph_edge_th,
+                           E, H, g.last_desc.data(), nullptr, nullptr, nullptr, nullptr, nullptr, 0, &ne, nullptr, nullptr, 0,
+                           &nt, nullptr, err);
 }
 
 }  // namespace sgs

@@ -454,7 +454,7 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
         SGS_HIP(c, hipEventRecord(c->ev_ds, s));
         SGS_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_ds, 0));
         if (c->profiling) hipEventRecord(c->ev_g0, c->stream2);
-        rg = graph_cluster_enqueue(c->stream2, c->gs, c->cluster, &c->st->n_c, n, cfg, &c->err);
+        rg = graph_cluster_enqueue(c->stream2, c->gs, c->cluster, &c->st->n_c, n, cfg, true, &c->err);
         if (rg) return rg;
         c->gworker.submit([c] {
             const double t_g0 = now_ms();

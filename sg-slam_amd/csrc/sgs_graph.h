@@ -22,11 +22,8 @@ struct ClassParams {
     double min_range, max_range;
 };
 
-struct CellSlot {
-    int32_t key;     // voxel_index, or INT_MIN when empty
-    int32_t count;   // points in the cell
-    int32_t start;   // offset of the cell's point list inside the class slice of cell_pts
-    int32_t cursor;
+struct CellSlot {  // 16 bytes of global scratch per slot: three int32 planes (key / list end / count) are carved from it
+    int32_t w[4];
 };
 
 struct ClusterStat {
@@ -42,8 +39,7 @@ struct GraphScratch {
     int32_t *bg_all = nullptr;        // background points in original order
     int32_t *counts = nullptr;        // [8]: per class n (5), n_fg, n_bg
     ClassParams *params = nullptr;    // [5]
-    int32_t *cell3 = nullptr;         // [N][4]: polar, range, azimuth, voxel_index per fg point (class order)
-    int32_t *cellslot = nullptr;      // [N]
+    int32_t *cell3 = nullptr;         // [N][4]: polar, range, azimuth cell coordinates per fg point (class order)
     int32_t *cell_pts = nullptr;      // [N]
     CellSlot *table = nullptr;        // [4N]
     int32_t *label = nullptr;         // [N] cluster label per fg point (class order)
@@ -55,15 +51,19 @@ struct GraphScratch {
     double *boxes_dev = nullptr;      // [kMaxNodes][8]
     double *edge_dev = nullptr;       // [kMaxNodes^2]
     int32_t *hist_dev = nullptr;      // [kMaxNodes][3*subinterval]
+    int32_t *n_boxes_dev = nullptr;   // node count for the edge kernel (0 when over kMaxNodes)
     // host staging
     ClassParams params_host[kNumFgClasses];
     std::vector<float> last_desc;     // node descriptors of the last processed scan
-    std::vector<ClusterStat> stat_host;
-    char *pinned = nullptr;           // 1 KiB host-pinned landing zone for counts + class parameters
+    std::vector<int> box_perm;        // reference-order box -> device-order box of the last scan
+    char *hostblk = nullptr;          // host-pinned, device-mapped block the kernels write their results into
+    char *hostblk_dev = nullptr;      // the same block as the device sees it
     int enqueued_upper = 0;
+    bool enqueued_graph = false;
 };
 
-constexpr int kMaxNodes = 1024;
+constexpr int kMaxNodes = 1024;       // graph nodes (boxes) per scan
+constexpr int kMaxClusters = 16384;   // non-empty instance clusters per scan (incl. those too small to become boxes)
 constexpr int kMaxHistCols = 3 * 256;
 
 int graph_scratch_alloc(GraphScratch &g, int N);
@@ -76,9 +76,9 @@ int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n
                   std::string *err);
 // pipeline form: enqueue (kernels only, no host sync) early, finish (+ graph) after the ICP loop
 int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper,
-                          const sgs_config &cfg, std::string *err);
+                          const sgs_config &cfg, bool with_graph, std::string *err);
 int graph_cluster_finish(hipStream_t s, GraphScratch &g, const int32_t *n_ptr, std::vector<double> *boxes, int *n_boxes,
-                         int32_t *point_cluster_host, int *n_fg, int *n_bg, std::string *err);
+                         int32_t *point_cluster_host, int *n_fg, int *n_bg, std::vector<int> *box_perm, std::string *err);
 int graph_finish_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, const sgs_config &cfg,
                       std::vector<double> *boxes, int *n_boxes, std::string *err);
 int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
