@@ -17,6 +17,7 @@
 // partials and folded by the solve kernel in fixed order: bit-reproducible run to run, no atomics.
 // This is gather/latency bound integer + fp work; there is no dense contraction, hence no MFMA.
 #include <climits>
+#include <type_traits>
 
 #include "sgs_device.h"
 
@@ -95,18 +96,22 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     const float c_relx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(relx)));
     const float c_rely = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(rely)));
     const float c_relz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(relz)));
-    // candidates: compacted voxel k, point p  <->  flat index c = k*cap + p; three rounds of 64 are
-    // fetched before the first distance is computed
+    // candidates: compacted voxel k, point p  <->  flat index c = k*cap + p, 64 per round.  Rounds are
+    // fetched in chunks of three, and the NEXT chunk's loads are issued before the current chunk's
+    // distances are computed, so a query with many occupied voxels still costs about one memory
+    // round trip.
     unsigned long long best = ~0ull;
     float bx = 0.f, by = 0.f, bz = 0.f;
     int blabel = 0;
     int ncand = 0;
     const int total = nf * m.cap;
     constexpr int kRounds = 3;
-    for (int c0 = 0; c0 < total; c0 += 64 * kRounds) {
+    struct Chunk {
         float4 q[kRounds];
         float rx[kRounds], ry[kRounds], rz[kRounds];
         int ord[kRounds];  // visiting ordinal v*cap + p of the candidate, -1 = none
+    };
+    auto fetch = [&](int c0, Chunk &ch) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
             const int c = c0 + r * 64 + lane;
@@ -115,26 +120,38 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
             const int kk = (k < nf ? k : 0) << 2;
             const int es = __builtin_amdgcn_ds_bpermute(kk, c_slot);
             const int em = __builtin_amdgcn_ds_bpermute(kk, c_meta);
-            rx[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_relx)));
-            ry[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_rely)));
-            rz[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_relz)));
+            ch.rx[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_relx)));
+            ch.ry[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_rely)));
+            ch.rz[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_relz)));
             const bool valid = k < nf && p < (em & 0xFF);
-            ord[r] = valid ? (em >> 8) * m.cap + p : -1;
-            if (valid) q[r] = m.pts[(size_t)es * m.cap + p];
+            ch.ord[r] = valid ? (em >> 8) * m.cap + p : -1;
+            if (valid) ch.q[r] = m.pts[(size_t)es * m.cap + p];
         }
+    };
+    auto score = [&](const Chunk &ch) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
-            if (ord[r] < 0) continue;
-            const float dx = q[r].x - rx[r], dy = q[r].y - ry[r], dz = q[r].z - rz[r];
+            if (ch.ord[r] < 0) continue;
+            const float dx = ch.q[r].x - ch.rx[r], dy = ch.q[r].y - ch.ry[r], dz = ch.q[r].z - ch.rz[r];
             const float d2 = dx * dx + (dy * dy + dz * dz);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)ord[r];
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)ch.ord[r];
             if (key < best) {
                 best = key;
-                bx = q[r].x; by = q[r].y; bz = q[r].z;
-                blabel = __float_as_int(q[r].w);
+                bx = ch.q[r].x; by = ch.q[r].y; bz = ch.q[r].z;
+                blabel = __float_as_int(ch.q[r].w);
             }
             ++ncand;
         }
+    };
+    if (total > 0) {
+        Chunk cur, nxt;
+        fetch(0, cur);
+        for (int c0 = 64 * kRounds; c0 < total; c0 += 64 * kRounds) {
+            fetch(c0, nxt);
+            score(cur);
+            cur = nxt;
+        }
+        score(cur);
     }
     unsigned long long wbest = best;
 #pragma unroll
@@ -248,6 +265,22 @@ __device__ inline void wave_lds_sync() {
 // Straight-line serial code for this (36-entry matrix in registers, constant indices) is ~2500
 // dependent fp64 instructions fetched cold once per launch and measured >10 us; this is ~10x
 // shorter.  Rounding differs from Eigen's operation order by ulps (pose bar: 1e-4 m / 1e-5 rad).
+// 1/d to within an ulp or two for normal d: v_rcp_f64 seed + two Newton steps (5 dependent
+// instructions; the IEEE division sequence is ~14).  d == 0 is the caller's case.
+__device__ inline double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+// value of lane `src` (compile-time constant) for the whole wave, through the scalar unit
+template <int SRC>
+__device__ inline double bcast_lane(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)u, SRC), hi = __builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), SRC);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ inline void wave_solve6(SolveLds &L, int lane) {
     // --- pivot sequence: selection sort (first maximum wins) on |diag| ---
     double mag[6];
@@ -278,35 +311,43 @@ __device__ inline void wave_solve6(SolveLds &L, int lane) {
     double B = L.A[pi * 6 + pj];
     double y = L.rhs[pi];
     // --- right-looking LDL^T ---
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double dk = __shfl(B, k * 7);
+    double dinv = 0.0;  // lane (i,*): 1 / D_i, 0 where |D_i| <= DBL_MIN
+    auto ldlt_step = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const double dk = bcast_lane<k * 7>(B);
         const bool valid = fabs(dk) > 0.0;
-        const double r = valid ? 1.0 / dk : 0.0;
+        const double r = valid ? fast_rcp(dk) : 0.0;
+        if (i == k) dinv = fabs(dk) > 2.2250738585072014e-308 ? r : 0.0;
         const double cik = __shfl(B, i * 6 + k), cjk = __shfl(B, j * 6 + k);
         const double lik = valid ? cik * r : cik;
         if (i > k && j > k) B -= valid ? lik * cjk : 0.0;
         if (i > k && j == k) B = lik;
-    }
+    };
+    ldlt_step(std::integral_constant<int, 0>{}); ldlt_step(std::integral_constant<int, 1>{});
+    ldlt_step(std::integral_constant<int, 2>{}); ldlt_step(std::integral_constant<int, 3>{});
+    ldlt_step(std::integral_constant<int, 4>{}); ldlt_step(std::integral_constant<int, 5>{});
     // --- forward substitution: y <- L^-1 y (every lane of row i carries y_i) ---
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const double yk = __shfl(y, k * 7);
+    auto fwd_step = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const double yk = bcast_lane<k * 7>(y);
         const double lik = __shfl(B, i * 6 + k);
         if (i > k) y -= lik * yk;
-    }
+    };
+    fwd_step(std::integral_constant<int, 0>{}); fwd_step(std::integral_constant<int, 1>{});
+    fwd_step(std::integral_constant<int, 2>{}); fwd_step(std::integral_constant<int, 3>{});
+    fwd_step(std::integral_constant<int, 4>{});
     // --- D^+ ---
-    {
-        const double di = __shfl(B, i * 7);
-        y = (fabs(di) > 2.2250738585072014e-308) ? y / di : 0.0;
-    }
+    y *= dinv;
     // --- backward substitution: y <- L^-T y ---
-#pragma unroll
-    for (int k = 5; k > 0; --k) {
-        const double yk = __shfl(y, k * 7);
+    auto bwd_step = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const double yk = bcast_lane<k * 7>(y);
         const double lki = __shfl(B, k * 6 + i);
         if (i < k) y -= lki * yk;
-    }
+    };
+    bwd_step(std::integral_constant<int, 5>{}); bwd_step(std::integral_constant<int, 4>{});
+    bwd_step(std::integral_constant<int, 3>{}); bwd_step(std::integral_constant<int, 2>{});
+    bwd_step(std::integral_constant<int, 1>{});
     // x = P^T y
     if (lane < 36 && i == j) L.x[pi] = y;
 }
@@ -316,12 +357,12 @@ __device__ inline void wave_solve6(SolveLds &L, int lane) {
 // device-mapped memory {iterations finished, done, -, -}; the host polls it instead of a copy +
 // stream sync.
 struct TailState {  // what the solve tail reads from DevState, fetched before the fold so the loads overlap it
-    Rigid T_icp, guess;
+    Rigid T_icp, T_total;
     long long corr, cand, probe;
     int32_t iter, max_iter;
 };
 __device__ inline TailState load_tail_state(const DevState *st) {
-    return TailState{st->T_icp, st->guess, st->icp_corr, st->icp_cand, st->icp_probe, st->icp_iter, st->icp_max_iter};
+    return TailState{st->T_icp, st->T_total, st->icp_corr, st->icp_cand, st->icp_probe, st->icp_iter, st->icp_max_iter};
 }
 
 __device__ inline void solve_and_update(DevState *st, const TailState &ts, const double *S, SolveLds &L, int lane,
@@ -335,14 +376,18 @@ __device__ inline void solve_and_update(DevState *st, const TailState &ts, const
     wave_lds_sync();
     wave_solve6(L, lane);
     wave_lds_sync();
-    if (lane != 0) return;
+    if (lane > 1) return;
     double x[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) x[i] = L.x[i];
+    // lane 0: T_icp <- est * T_icp; lane 1: T_total <- est * T_total (= T_icp_new * guess), side by side
     const Rigid est = rigid_exp_small(D3{x[0], x[1], x[2]}, D3{x[3], x[4], x[5]});
-    const Rigid T_icp = compose_fast(est, ts.T_icp);
-    st->T_icp = T_icp;
-    st->T_total = compose_fast(T_icp, ts.guess);
+    const Rigid upd = compose_fast(est, lane == 0 ? ts.T_icp : ts.T_total);
+    if (lane == 1) {
+        st->T_total = upd;
+        return;
+    }
+    st->T_icp = upd;
     st->icp_corr = ts.corr + (long long)S[16];
     st->icp_cand = ts.cand + (long long)S[17];
     st->icp_probe = ts.probe + (long long)S[18];

@@ -237,6 +237,14 @@ SGS_HD void solve6_static(double (&A)[6][6], const double (&b)[6], double (&x)[6
     for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
+// 1/sqrt(s) for s = |q|^2 of a product of unit quaternions (s = 1 + e, |e| ~ 1e-15): the series
+// 1 - e/2 + 3e^2/8 is exact to double precision there; anything farther from 1 takes the sqrt.
+SGS_HD double inv_sqrt_near1(double s) {
+    const double e = s - 1.0;
+    if (fabs(e) < 1e-5) return 1.0 + e * (-0.5 + e * (0.375 - 0.3125 * e));
+    return 1.0 / sqrt(s);
+}
+
 // exp for the Gauss-Newton updates on the device.  The updates are small (|omega| well below 0.1 rad
 // after the first iteration), so below |omega|^2 = 1e-2 every trigonometric coefficient is a short
 // even power series in theta (no sqrt, no sincos, no cancellation; truncation < 1e-19 relative);
@@ -267,7 +275,7 @@ SGS_HD Rigid rigid_exp_small(D3 v, D3 w) {
     }
     Rigid T;
     T.qw = re; T.qx = im * w.x; T.qy = im * w.y; T.qz = im * w.z;
-    const double rn = 1.0 / sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
+    const double rn = inv_sqrt_near1(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
     T.qw *= rn; T.qx *= rn; T.qy *= rn; T.qz *= rn;
     const D3 wv = crs(w, v);
     const D3 wwv = crs(w, wv);
@@ -281,7 +289,7 @@ SGS_HD Rigid compose_fast(const Rigid &a, const Rigid &b) {
     r.qx = a.qw * b.qx + a.qx * b.qw + a.qy * b.qz - a.qz * b.qy;
     r.qy = a.qw * b.qy + a.qy * b.qw + a.qz * b.qx - a.qx * b.qz;
     r.qz = a.qw * b.qz + a.qz * b.qw + a.qx * b.qy - a.qy * b.qx;
-    const double rn = 1.0 / sqrt(r.qw * r.qw + r.qx * r.qx + r.qy * r.qy + r.qz * r.qz);
+    const double rn = inv_sqrt_near1(r.qw * r.qw + r.qx * r.qx + r.qy * r.qy + r.qz * r.qz);
     r.qw *= rn; r.qx *= rn; r.qy *= rn; r.qz *= rn;
     r.t = add(a.t, rotate(a, b.t));
     return r;
