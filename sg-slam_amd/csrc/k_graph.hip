@@ -75,8 +75,10 @@ __global__ __launch_bounds__(kBlock) void route_count_kernel(CloudView in, const
 // thread owns a run of consecutive blocks for all 7 categories at once, the 256 run sums are scanned
 // with wave shuffles + one LDS hop.
 __global__ __launch_bounds__(kBlock) void route_totals_kernel(int32_t *__restrict__ blockcnt, int nblocks,
-                                                              int32_t *__restrict__ counts, ClassParams *__restrict__ params) {
+                                                              int32_t *__restrict__ counts, ClassParams *__restrict__ params,
+                                                              unsigned long long *__restrict__ range_ext) {
     __shared__ int wsum[kBlock / 64][8];
+    if (threadIdx.x < 2 * kNumFgClasses) range_ext[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull;  // [class]{min, max}
     __shared__ int tot[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (nblocks + kBlock - 1) / kBlock;
@@ -142,11 +144,42 @@ __global__ __launch_bounds__(kBlock) void route_totals_kernel(int32_t *__restric
     }
 }
 
+struct ClusterConsts {
+    double dA, dR, dP;
+    double min_az;  // -24.8 deg in rad, computed on the host exactly as the reference writes it
+    int width, height;
+};
+
+__device__ inline double polar_angle(double x, double y) {  // F/SemanticCluster.cpp:10-20
+    double t = 0;
+    if (x == 0 && y == 0) t = 0;
+    else if (y >= 0) t = atan2(y, x);
+    else if (y < 0) t = atan2(y, x) + 2 * M_PI;
+    return t;
+}
+
+__device__ inline unsigned long long enc_double(double d) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __host__ inline double dec_double(unsigned long long e) {
+    const unsigned long long b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
+    double d;
+    memcpy(&d, &b, sizeof(d));
+    return d;
+}
+
+// Order-preserving scatter of the point indices into the 7 category lists, and - grid-wide, where the
+// fp64 atan2s cost nothing in latency - the polar / azimuth cell coordinates and the planar range of
+// every foreground point (calculateAPR, F/SemanticCluster.cpp:22-36, and the index expressions of
+// :50-54 / :118-121), plus the per-class range extrema the range index needs.
 __global__ __launch_bounds__(kBlock) void route_scatter_kernel(CloudView in, const int32_t *__restrict__ n_ptr,
                                                                const int32_t *__restrict__ blockbase,
-                                                               const ClassParams *__restrict__ params,
+                                                               const ClassParams *__restrict__ params, ClusterConsts K,
                                                                int32_t *__restrict__ fg_order, int32_t *__restrict__ fg_all,
-                                                               int32_t *__restrict__ bg_all) {
+                                                               int32_t *__restrict__ bg_all, int32_t *__restrict__ pol_azi,
+                                                               double *__restrict__ apr_range,
+                                                               unsigned long long *__restrict__ range_ext) {
     const int n = *n_ptr;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     int cls = -1;
@@ -157,6 +190,8 @@ __global__ __launch_bounds__(kBlock) void route_scatter_kernel(CloudView in, con
         bg = is_background(L);
     }
     __shared__ int wcnt[7][kBlock / 64];
+    __shared__ unsigned long long s_ext[2 * kNumFgClasses];
+    if (threadIdx.x < 2 * kNumFgClasses) s_ext[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int myrank[7];
 #pragma unroll
@@ -173,25 +208,32 @@ __global__ __launch_bounds__(kBlock) void route_scatter_kernel(CloudView in, con
         for (int w = 0; w < wave; ++w) base += wcnt[k][w];
         const bool f = k < 5 ? (cls == k) : (k == 5 ? cls >= 0 : bg);
         if (f) {
-            if (k < 5) fg_order[params[k].start + base + myrank[k]] = i;
-            else if (k == 5) fg_all[base + myrank[k]] = i;
-            else bg_all[base + myrank[k]] = i;
+            if (k < 5) {
+                const int pos = params[k].start + base + myrank[k];
+                fg_order[pos] = i;
+                const double x = in.x[i], y = in.y[i], z = in.z[i];
+                const double polar = polar_angle(x, y);
+                const double range = sqrt(x * x + y * y);
+                const double azimuth = atan2(z, range);
+                pol_azi[2 * (size_t)pos] = (int)(polar * 180 / M_PI / K.dP);
+                pol_azi[2 * (size_t)pos + 1] = (int)(((azimuth - K.min_az) * 180 / M_PI) / K.dA);
+                apr_range[pos] = range;
+                const unsigned long long e = enc_double(range);
+                atomicMin(&s_ext[2 * k], e);
+                atomicMax(&s_ext[2 * k + 1], e);
+            } else if (k == 5) {
+                fg_all[base + myrank[k]] = i;
+            } else {
+                bg_all[base + myrank[k]] = i;
+            }
         }
     }
-}
-
-struct ClusterConsts {
-    double dA, dR, dP;
-    double min_az;  // -24.8 deg in rad, computed on the host exactly as the reference writes it
-    int width, height;
-};
-
-__device__ inline double polar_angle(double x, double y) {  // F/SemanticCluster.cpp:10-20
-    double t = 0;
-    if (x == 0 && y == 0) t = 0;
-    else if (y >= 0) t = atan2(y, x);
-    else if (y < 0) t = atan2(y, x) + 2 * M_PI;
-    return t;
+    __syncthreads();
+    if (threadIdx.x < 2 * kNumFgClasses) {
+        const unsigned long long e = s_ext[threadIdx.x];
+        if (threadIdx.x & 1) { if (e != 0ull) atomicMax(&range_ext[threadIdx.x], e); }
+        else if (e != ~0ull) atomicMin(&range_ext[threadIdx.x], e);
+    }
 }
 
 __device__ inline int find_root(const int32_t *parent, int v) {
@@ -203,17 +245,6 @@ __device__ inline int find_root(const int32_t *parent, int v) {
 }
 
 __device__ inline uint32_t cell_hash(int key) { return (uint32_t)key * 2654435761u; }
-
-__device__ inline unsigned long long enc_double(double d) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __host__ inline double dec_double(unsigned long long e) {
-    const unsigned long long b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
-    double d;
-    memcpy(&d, &b, sizeof(d));
-    return d;
-}
 
 // memory traffic between lanes of ONE wavefront (the greedy walk runs on wave 0 alone while the other
 // waves wait at the block barrier behind it, so it must not use the block barrier itself)
@@ -245,215 +276,168 @@ __device__ inline int block_excl_scan(int v, int *wsum /*shared [kBlock/64]*/, i
     return base + incl - v;
 }
 
-// Per-class working set of the clustering.  All of it is touched by the serial greedy walk, one
-// dependent access after another, so it lives in LDS whenever the class fits (a global round trip
-// is ~10x an LDS one): label n, parent n+1, cell coordinates 3n, cell point lists n, cell table
-// 3 x cap words.  Classes too large for that run the same code on global scratch.
+// ---- curved-voxel clustering of one class (F/SemanticCluster.cpp:109-174), at CELL granularity ----
+// The reference walks the points in input order; an unlabelled point i (a "seed") gathers the points
+// of its 27 neighbour cells in z/y/x cell order, each cell's points in input order, and:
+//   no labelled neighbour  -> new label for i and all of them;
+//   else                   -> i takes the first labelled neighbour's label; every later labelled
+//                             neighbour with another label merges i's cluster INTO that label
+//                             (relabel scan); every later unlabelled neighbour takes i's label;
+//                             neighbours BEFORE the first labelled one are left alone.
+// Points are therefore labelled a whole cell at a time, except a seed whose own cell precedes its
+// first labelled neighbour cell: it alone is labelled and its cell mates become seeds later.  When
+// seed i runs, every point with a smaller index is labelled, so a cell "has a labelled point" iff it
+// was swept (whole-cell labelled) or its smallest point index is < i, and all labelled points of a
+// cell share one root.  The walk thus needs per cell {swept, smallest index, one label value} and a
+// union-find over label values (parent[old] = new reproduces the relabel scans' final values); the
+// per-point lists, their sort and the per-point label array of a literal transcription are gone.
+// One exception keeps a per-point label: a cell whose azimuth index lies outside [0, height) (or
+// whose polar index equals width) is skipped by find_neighbors for every seed, its own points
+// included, so it is never swept: each of its points is a seed that is labelled alone.
+// What stays serial is one step per seed, on wave 0: lanes 0..26 hold the 27 neighbour cells.
 constexpr int kLdsWords = 36 * 1024;  // 144 KiB of the CU's 160 KiB
 struct ClusterMem {
-    int32_t *label;   // [n] cluster label per point (class order), -1 = none yet
-    int32_t *parent;  // [n+1] union-find over label values; [1..n] doubles as the point->slot map while building
-    int32_t *c3;      // [3n] polar, range, azimuth cell coordinates
-    int32_t *cpts;    // [n] point lists of the cells, concatenated
-    int32_t *tkey, *tend, *tcount;  // [cap] cell table: voxel_index / INT_MIN, END of the point list, points
+    int32_t *cslot;   // [n] table slot of every point's cell
+    int32_t *plabel;  // [n] label of a point whose cell no neighbour list contains (see walk), else unused
+    int32_t *parent;  // [n+1] union-find over label values 1..
+    int32_t *tkey;    // [cap] cell table: voxel_index, INT_MIN = empty
+    int32_t *tmin;    // [cap] smallest point index in the cell
+    int32_t *tlab;    // [cap] a label value of the cell's cluster, -1 = none yet
+    int32_t *tswept;  // [cap] 1 = every point of the cell is labelled, 2 = cell outside every neighbour list
+    int32_t *tpol, *trng, *tazi;  // [cap] cell coordinates
+    int32_t *tcidx;   // [cap] dense index of the occupied cell (neighbour-list row)
+    int32_t *nbr;     // [nbr_cells][27] slots of the neighbour cells in visiting order, -1 = none; may be null
+    int nbr_cells;
     int tmask;
 };
 
+// slot of neighbour `k` (0..26, z/y/x order of find_neighbors :72-99) of the cell at `own`, or -1
+__device__ __forceinline__ int neighbour_slot(const ClusterMem &M, int own, int k, int length, int width, int height) {
+    const int z = M.tazi[own] + k / 9 - 1, y = M.trng[own] + (k / 3) % 3 - 1, x = M.tpol[own] + k % 3 - 1;
+    if (z < 0 || z > height - 1 || y < 0 || y > length - 1) return -1;
+    int px = x;
+    if (x < 0) px = width - 1;
+    if (x > width - 1) px = 0;
+    const int key = (px * length + y) + z * length * width;
+    uint32_t s = cell_hash(key) & (uint32_t)M.tmask;
+    for (int step = 0; step <= M.tmask; ++step) {
+        const int kk = M.tkey[s];
+        if (kk == key) return (int)s;
+        if (kk == INT_MIN) return -1;
+        s = (s + 1u) & (uint32_t)M.tmask;
+    }
+    return -1;
+}
+
 template <bool LDS>
 __device__ __forceinline__ void cluster_class_body(const int c, const int n, const CloudView in, ClassParams *params,
-                                                   const int32_t *__restrict__ order, const ClusterConsts K,
-                                                   const ClusterMem M, ClusterStat *stat_out /*global, [v], v = 1..*/,
+                                                   const int32_t *__restrict__ order, const int32_t *__restrict__ pol_azi,
+                                                   const double *__restrict__ apr_range, const double minR, const double maxR,
+                                                   const ClusterConsts K, const ClusterMem M, ClusterStat *stat_out /*global, [v], v = 1..*/,
                                                    ClusterStat *stat_lds, const int stat_lds_cap,
                                                    int32_t *__restrict__ pt_cluster) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int32_t *const label = M.label, *const parent = M.parent, *const c3 = M.c3, *const cpts = M.cpts;
-    int32_t *const tkey = M.tkey, *const tend = M.tend, *const tcount = M.tcount;
-    int32_t *const cslot = parent + 1;
-    const int tmask = M.tmask;
+    int32_t *const cslot = M.cslot, *const parent = M.parent;
+    const int tmask = M.tmask, cap = tmask + 1;
+    __shared__ int s_current, s_ncells;
 
-    __shared__ double s_min[kBlock / 64], s_max[kBlock / 64];
-    __shared__ double s_minR;
-    __shared__ int s_len, s_current;
-    __shared__ int s_wsum[kBlock / 64];
-    __shared__ int s_excl[28], s_cstart[27];
-
-    // ---- A: calculateAPR range extrema (:22-36)
-    double mn = 1.7976931348623157e308, mx = 2.2250738585072014e-308;
-    for (int j = tid; j < n; j += kBlock) {
-        const int oi = order[j];
-        const double x = in.x[oi], y = in.y[oi];
-        const double r = sqrt(x * x + y * y);
-        if (r < mn) mn = r;
-        if (r > mx) mx = r;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double a = __shfl_down(mn, o), b = __shfl_down(mx, o);
-        mn = a < mn ? a : mn;
-        mx = b > mx ? b : mx;
-    }
-    if (lane == 0) { s_min[wave] = mn; s_max[wave] = mx; }
-    for (int s = tid; s <= tmask; s += kBlock) { tkey[s] = INT_MIN; tcount[s] = 0; }
-    __syncthreads();
+    // ---- A: grid dimensions (:37-39)
+    const int length = (int)((maxR - minR) / K.dR) + 1, width = K.width, height = K.height;
     if (tid == 0) {
-        double a = s_min[0], b = s_max[0];
-        for (int w = 1; w < kBlock / 64; ++w) {
-            a = s_min[w] < a ? s_min[w] : a;
-            b = s_max[w] > b ? s_max[w] : b;
-        }
-        s_minR = a;
-        s_len = (int)((b - a) / K.dR) + 1;  // :37
-        params[c].min_range = a; params[c].max_range = b;
-        params[c].length = s_len; params[c].width = K.width; params[c].height = K.height;
+        params[c].min_range = minR; params[c].max_range = maxR;
+        params[c].length = length; params[c].width = width; params[c].height = height;
+        s_ncells = 0;
     }
+    for (int s = tid; s < cap; s += kBlock) { M.tkey[s] = INT_MIN; M.tmin[s] = INT_MAX; M.tlab[s] = -1; M.tswept[s] = 0; }
     __syncthreads();
-    const double minR = s_minR;
-    const int length = s_len, width = K.width, height = K.height;
 
-    // ---- B: cell of every point (:50-54) + cell table insert
+    // ---- B: cell of every point (:50-54) -> cell table (key, smallest point index, coordinates)
     for (int j = tid; j < n; j += kBlock) {
-        const int oi = order[j];
-        const double x = in.x[oi], y = in.y[oi], z = in.z[oi];
-        const double polar = polar_angle(x, y);
-        const double range = sqrt(x * x + y * y);
-        const double azimuth = atan2(z, range);
-        const int azi = (int)(((azimuth - K.min_az) * 180 / M_PI) / K.dA);
-        const int pol = (int)(polar * 180 / M_PI / K.dP);
-        const int rng = (int)((range - minR) / K.dR);
+        const int pol = pol_azi[2 * (size_t)j], azi = pol_azi[2 * (size_t)j + 1];
+        const int rng = (int)((apr_range[j] - minR) / K.dR);
         const int vidx = (pol * length + rng) + azi * length * width;
-        c3[3 * j] = pol; c3[3 * j + 1] = rng; c3[3 * j + 2] = azi;
         uint32_t s = cell_hash(vidx) & (uint32_t)tmask;
         while (true) {
-            const int cur = atomicCAS(&tkey[s], INT_MIN, vidx);
-            if (cur == INT_MIN || cur == vidx) break;
+            const int cur = atomicCAS(&M.tkey[s], INT_MIN, vidx);
+            if (cur == INT_MIN) {  // this thread created the cell
+                M.tpol[s] = pol; M.trng[s] = rng; M.tazi[s] = azi;
+                M.tcidx[s] = atomicAdd(&s_ncells, 1);
+                break;
+            }
+            if (cur == vidx) break;
             s = (s + 1u) & (uint32_t)tmask;
         }
-        atomicAdd(&tcount[s], 1);
+        atomicMin(&M.tmin[s], j);
         cslot[j] = (int)s;
-        label[j] = -1;
     }
     __syncthreads();
-
-    // ---- C: exclusive scan of the cell counts -> list starts (kept in tend, advanced to the ends by D)
-    const int cap = tmask + 1;
-    const int per = (cap + kBlock - 1) / kBlock;
-    {
-        int sum = 0;
-        for (int s = tid * per; s < (tid + 1) * per && s < cap; ++s) sum += tcount[s];
-        int total;
-        int run = block_excl_scan(sum, s_wsum, &total);
-        for (int s = tid * per; s < (tid + 1) * per && s < cap; ++s) {
-            tend[s] = run;
-            run += tcount[s];
-        }
-    }
-    __syncthreads();
-    // ---- D: fill the per-cell lists, then sort each by point index (insertion order of :58)
-    for (int j = tid; j < n; j += kBlock) cpts[atomicAdd(&tend[cslot[j]], 1)] = j;
-    __syncthreads();
-    for (int s = tid; s < cap; s += kBlock) {
-        const int cnt = tcount[s], st = tend[s] - cnt;
-        for (int a = 1; a < cnt; ++a) {
-            const int v = cpts[st + a];
-            int b = a - 1;
-            while (b >= 0 && cpts[st + b] > v) {
-                cpts[st + b + 1] = cpts[st + b];
-                --b;
-            }
-            cpts[st + b + 1] = v;
+    // ---- C: neighbour lists of the occupied cells (27 lookups each), when they fit
+    const bool lists = M.nbr != nullptr && s_ncells <= M.nbr_cells;
+    if (lists) {
+        for (int e = tid; e < 27 * cap; e += kBlock) {
+            const int s = e / 27, k = e - 27 * s;
+            if (M.tkey[s] != INT_MIN) M.nbr[27 * M.tcidx[s] + k] = neighbour_slot(M, s, k, length, width, height);
         }
     }
     __syncthreads();
 
-    // ---- F: the greedy labelling (:109-174), seeds in input order, wave 0 alone
+    // ---- F: the walk over the seeds, wave 0 alone
     if (wave == 0) {
         int current = 0;
+        int last = -1;
         for (int base = 0; base < n; base += 64) {
             while (true) {
                 const int jj = base + lane;
-                const int lab = jj < n ? label[jj] : 0;
-                const unsigned long long um = __ballot(jj < n && lab == -1);
+                const int sl = jj < n ? cslot[jj] : 0;
+                const bool unl = jj < n && jj > last && M.tswept[sl] != 1;
+                const unsigned long long um = __ballot(unl);
                 if (!um) break;
-                const int i = base + __ffsll((long long)um) - 1;  // next unlabelled point = seed
-                const int pol = c3[3 * i], rng = c3[3 * i + 1], azi = c3[3 * i + 2];
-                // neighbour cells in z / y / x order (find_neighbors :72-99)
-                int ccount = 0, cstart = 0;
-                if (lane < 27) {
-                    const int z = azi + lane / 9 - 1, y = rng + (lane / 3) % 3 - 1, x = pol + lane % 3 - 1;
-                    if (!(z < 0 || z > height - 1) && !(y < 0 || y > length - 1)) {
-                        int px = x;
-                        if (x < 0) px = width - 1;
-                        if (x > width - 1) px = 0;
-                        const int key = (px * length + y) + z * length * width;
-                        uint32_t s = cell_hash(key) & (uint32_t)tmask;
-                        for (int step = 0; step <= tmask; ++step) {
-                            const int k = tkey[s];
-                            if (k == key) { ccount = tcount[s]; cstart = tend[s] - ccount; break; }
-                            if (k == INT_MIN) break;
-                            s = (s + 1u) & (uint32_t)tmask;
-                        }
-                    }
+                const int fl0 = __ffsll((long long)um) - 1;
+                const int i = base + fl0;  // next unlabelled point = seed
+                last = i;
+                const int own = __shfl(sl, fl0);
+                int ns = -1;
+                if (lane < 27) ns = lists ? M.nbr[27 * M.tcidx[own] + lane] : neighbour_slot(M, own, lane, length, width, height);
+                const bool exist = ns >= 0;
+                int lb = -1;
+                bool haslab = false;
+                if (exist) {
+                    haslab = M.tswept[ns] != 0 || M.tmin[ns] < i;
+                    lb = M.tlab[ns];
                 }
-                int incl = ccount;
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    const int up = __shfl_up(incl, o);
-                    if (lane >= o) incl += up;
-                }
-                const int m = __shfl(incl, 26);
-                if (lane < 27) { s_excl[lane] = incl - ccount; s_cstart[lane] = cstart; }
-                if (lane == 27) s_excl[27] = m;
-                wave_sync();
-                int oc = -1;
-                for (int t0 = 0; t0 < m; t0 += 64) {
-                    const int t = t0 + lane;
-                    const bool valid = t < m;
-                    int nj = -1, root = -1;
-                    if (valid) {
-                        int k = 0;
-#pragma unroll
-                        for (int step = 16; step > 0; step >>= 1)
-                            if (k + step < 27 && s_excl[k + step] <= t) k += step;
-                        nj = cpts[s_cstart[k] + (t - s_excl[k])];
-                        const int lj = label[nj];
-                        if (lj > 0) root = find_root(parent, lj);
-                    }
-                    unsigned long long active = __ballot(valid);
-                    if (oc == -1) {
-                        const unsigned long long labelled = __ballot(valid && root != -1);
-                        if (!labelled) continue;  // everything here precedes the first labelled neighbour
-                        const int fl = __ffsll((long long)labelled) - 1;
-                        oc = __shfl(root, fl);
-                        active &= ~((2ull << fl) - 1ull);  // positions after the first labelled one
-                    }
-                    const bool mine = (active >> lane) & 1ull;
-                    while (true) {
-                        const unsigned long long diff = __ballot(mine && root != -1 && root != oc);
+                const unsigned long long labelled = __ballot(haslab);
+                const bool own_listed = __ballot(exist && ns == own) != 0ull;
+                int seed_label;
+                if (!labelled) {  // nobody around is labelled: new cluster for the seed and all 27 cells
+                    ++current;
+                    if (lane == 0) parent[current] = current;
+                    if (exist) { M.tswept[ns] = 1; M.tlab[ns] = current; }
+                    seed_label = current;
+                } else {
+                    const int f = __ffsll((long long)labelled) - 1;
+                    int root = haslab ? find_root(parent, lb) : -1;
+                    int oc = __shfl(root, f);
+                    const bool later = exist && lane > f;
+                    while (true) {  // later labelled cells with another root: mergeClusters(oc -> nc) (:101-107)
+                        const unsigned long long diff = __ballot(later && root != -1 && root != oc);
                         if (!diff) break;
                         const int dl = __ffsll((long long)diff) - 1;
                         const int nc = __shfl(root, dl);
-                        if (lane == 0) parent[oc] = nc;  // mergeClusters(oc -> nc)
+                        if (lane == 0) parent[oc] = nc;
                         if (root == oc) root = nc;
                         oc = nc;
                     }
-                    if (mine && root == -1) label[nj] = oc;
-                    wave_sync();
-                }
-                if (oc == -1) {  // nobody around was labelled: new cluster for the seed and all neighbours
-                    ++current;
-                    if (lane == 0) { parent[current] = current; label[i] = current; }
-                    for (int t0 = 0; t0 < m; t0 += 64) {
-                        const int t = t0 + lane;
-                        if (t < m) {
-                            int k = 0;
-#pragma unroll
-                            for (int step = 16; step > 0; step >>= 1)
-                                if (k + step < 27 && s_excl[k + step] <= t) k += step;
-                            label[cpts[s_cstart[k] + (t - s_excl[k])]] = current;
-                        }
+                    if (exist && lane >= f) {
+                        M.tswept[ns] = 1;
+                        if (!haslab) M.tlab[ns] = oc;
                     }
-                } else if (lane == 0) {
-                    label[i] = oc;
+                    // the seed's own cell precedes the first labelled cell: the seed alone is labelled
+                    if (exist && lane < f && ns == own) M.tlab[ns] = oc;
+                    seed_label = oc;
+                }
+                if (!own_listed && lane == 0) {
+                    M.tswept[own] = 2;
+                    M.plabel[i] = seed_label;
                 }
                 wave_sync();
             }
@@ -466,7 +450,7 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
     __syncthreads();
 
     // ---- G: per-cluster count / first index / AABB (:278-304), final label of every point.  The
-    // accumulators sit in LDS (the cell table's words, free now) unless there are too many clusters.
+    // accumulators sit in LDS (the neighbour lists' words, free now) unless there are too many clusters.
     const int current = s_current;
     ClusterStat *const acc = (LDS && current <= stat_lds_cap) ? stat_lds : stat_out;  // generic pointer: flat atomics
     for (int v = 1 + tid; v <= current; v += kBlock) {
@@ -479,7 +463,8 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
     }
     __syncthreads();
     for (int j = tid; j < n; j += kBlock) {
-        const int v = find_root(parent, label[j]);
+        const int sl = cslot[j];
+        const int v = find_root(parent, M.tswept[sl] == 2 ? M.plabel[j] : M.tlab[sl]);
         const int oi = order[j];
         pt_cluster[oi] = v;
         ClusterStat *e = acc + v;
@@ -496,44 +481,55 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
     }
 }
 
-// one workgroup per class
+// one workgroup per class; the working set lives in LDS when the class fits, else in global scratch
 __global__ __launch_bounds__(kBlock) void cluster_class_kernel(CloudView in, ClassParams *params,
-                                                               const int32_t *__restrict__ fg_order, ClusterConsts K,
-                                                               int32_t *cell3, int32_t *cell_pts, int32_t *table_all,
-                                                               int32_t *label_all, int32_t *parent_all, ClusterStat *stat,
-                                                               int32_t *__restrict__ pt_cluster) {
+                                                               const int32_t *__restrict__ fg_order,
+                                                               const int32_t *__restrict__ pol_azi,
+                                                               const double *__restrict__ apr_range,
+                                                               const unsigned long long *__restrict__ range_ext, ClusterConsts K,
+                                                               int32_t *cslot_all, int32_t *plabel_all, int32_t *table_all,
+                                                               int32_t *parent_all,
+                                                               ClusterStat *stat, int32_t *__restrict__ pt_cluster) {
     __shared__ __align__(16) int32_t smem[kLdsWords];
     const int c = blockIdx.x;
     const int n = params[c].n;
     if (n <= 0) return;
     const int start = params[c].start;
+    const double minR = dec_double(range_ext[2 * c]), maxR = dec_double(range_ext[2 * c + 1]);
     ClusterStat *stat_out = stat + start + c;  // indexed by label value 1..n
     int cap = 1;
     while (cap < n + n / 2 + 1) cap <<= 1;
-    if (6 * n + 4 + 3 * cap <= kLdsWords) {
+    const int fixed = 3 * n + 1 + 8 * cap;
+    if (fixed + 64 <= kLdsWords) {
         ClusterMem M;
-        M.label = smem;
-        M.parent = smem + n;
-        M.c3 = smem + 2 * n + 1;
-        M.cpts = smem + 5 * n + 1;
-        int32_t *tab = smem + 6 * n + 1;
-        tab += (4 - ((6 * n + 1) & 3)) & 3;  // 16-byte aligned: the words double as ClusterStat records later
-        M.tkey = tab; M.tend = tab + cap; M.tcount = tab + 2 * cap;
+        M.cslot = smem;
+        M.plabel = smem + n;
+        M.parent = smem + 2 * n;
+        int32_t *t = smem + 3 * n + 1;
+        M.tkey = t; M.tmin = t + cap; M.tlab = t + 2 * cap; M.tswept = t + 3 * cap;
+        M.tpol = t + 4 * cap; M.trng = t + 5 * cap; M.tazi = t + 6 * cap; M.tcidx = t + 7 * cap;
+        int32_t *rest = t + 8 * cap;
+        rest += (4 - ((3 * n + 1) & 3)) & 3;  // 16-byte aligned: these words double as ClusterStat records later
+        const int room = (int)(smem + kLdsWords - rest);
+        M.nbr = rest;
+        M.nbr_cells = room / 27;
         M.tmask = cap - 1;
-        const int room = (int)(smem + kLdsWords - tab);  // >= 3 * cap - 3
-        cluster_class_body<true>(c, n, in, params, fg_order + start, K, M, stat_out, reinterpret_cast<ClusterStat *>(tab),
-                                 room / 16 - 1, pt_cluster);
+        cluster_class_body<true>(c, n, in, params, fg_order + start, pol_azi + 2 * (size_t)start, apr_range + start, minR, maxR, K,
+                                 M, stat_out, reinterpret_cast<ClusterStat *>(rest), room / 16 - 1, pt_cluster);
     } else {
         ClusterMem M;
-        M.label = label_all + start;
+        M.cslot = cslot_all + start;
+        M.plabel = plabel_all + start;
         M.parent = parent_all + start + c;
-        M.c3 = cell3 + 4 * (size_t)start;
-        M.cpts = cell_pts + start;
-        const int gcap = params[c].table_mask + 1;  // pow2 >= 2n, slice of 16n words
-        int32_t *tab = table_all + 16 * (size_t)start;
-        M.tkey = tab; M.tend = tab + gcap; M.tcount = tab + 2 * (size_t)gcap;
+        const int gcap = params[c].table_mask + 1;  // pow2 >= 2n <= 4n, slice of 32n words
+        int32_t *t = table_all + 32 * (size_t)start;
+        M.tkey = t; M.tmin = t + gcap; M.tlab = t + 2 * (size_t)gcap; M.tswept = t + 3 * (size_t)gcap;
+        M.tpol = t + 4 * (size_t)gcap; M.trng = t + 5 * (size_t)gcap; M.tazi = t + 6 * (size_t)gcap; M.tcidx = t + 7 * (size_t)gcap;
+        M.nbr = nullptr;
+        M.nbr_cells = 0;
         M.tmask = gcap - 1;
-        cluster_class_body<false>(c, n, in, params, fg_order + start, K, M, stat_out, nullptr, 0, pt_cluster);
+        cluster_class_body<false>(c, n, in, params, fg_order + start, pol_azi + 2 * (size_t)start, apr_range + start, minR, maxR, K,
+                                  M, stat_out, nullptr, 0, pt_cluster);
     }
 }
 
@@ -765,8 +761,9 @@ int graph_scratch_alloc(GraphScratch &g, int N) {
     g.N = N;
     const size_t n = (size_t)N;
     bool ok = galloc(&g.cat_blockcnt, (n / kBlock + 2) * 8) && galloc(&g.fg_order, n) && galloc(&g.fg_all, n) &&
-              galloc(&g.bg_all, n) && galloc(&g.counts, 8) && galloc(&g.params, kNumFgClasses) && galloc(&g.cell3, n * 4) &&
-              galloc(&g.cell_pts, n) && galloc(&g.table, n * 4 + 16) && galloc(&g.label, n) &&
+              galloc(&g.bg_all, n) && galloc(&g.counts, 8) && galloc(&g.params, kNumFgClasses) && galloc(&g.pol_azi, n * 2 + 2) &&
+              galloc(&g.apr_range, n + 1) && galloc(&g.range_ext, 2 * kNumFgClasses) && galloc(&g.cslot, n) && galloc(&g.plabel, n) &&
+              galloc(&g.table, n * 32 + 64) &&
               galloc(&g.parent, n + 16) && galloc(&g.stat, n + 16) && galloc(&g.pt_cluster, n) &&
               galloc(&g.boxes_dev, (size_t)kMaxClusters * 8) && galloc(&g.edge_dev, (size_t)kMaxNodes * kMaxNodes) &&
               galloc(&g.hist_dev, (size_t)kMaxNodes * kMaxHistCols) && galloc(&g.n_boxes_dev, 4);
@@ -777,8 +774,8 @@ int graph_scratch_alloc(GraphScratch &g, int N) {
 }
 
 void graph_scratch_free(GraphScratch &g) {
-    void *ps[] = {g.cat_blockcnt, g.fg_order, g.fg_all, g.bg_all, g.counts, g.params, g.cell3, g.cell_pts,
-                  g.table, g.label, g.parent, g.stat, g.pt_cluster, g.boxes_dev, g.edge_dev, g.hist_dev, g.n_boxes_dev};
+    void *ps[] = {g.cat_blockcnt, g.fg_order, g.fg_all, g.bg_all, g.counts, g.params, g.pol_azi, g.apr_range,
+                  g.range_ext, g.cslot, g.plabel, g.table, g.parent, g.stat, g.pt_cluster, g.boxes_dev, g.edge_dev, g.hist_dev, g.n_boxes_dev};
     for (void *p : ps)
         if (p) hipFree(p);
     if (g.hostblk) hipHostFree(g.hostblk);
@@ -810,9 +807,6 @@ int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const in
     }
     const int nb = (n_upper + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(route_count_kernel, dim3(nb), dim3(kBlock), 0, s, in, n_ptr, g.cat_blockcnt, g.pt_cluster);
-    hipLaunchKernelGGL(route_totals_kernel, dim3(1), dim3(kBlock), 0, s, g.cat_blockcnt, nb, g.counts, g.params);
-    hipLaunchKernelGGL(route_scatter_kernel, dim3(nb), dim3(kBlock), 0, s, in, n_ptr, g.cat_blockcnt, g.params, g.fg_order,
-                       g.fg_all, g.bg_all);
     ClusterConsts K;
     K.dA = cfg.deltaA; K.dR = cfg.deltaR; K.dP = cfg.deltaP;
     // F/SemanticCluster.hpp:46-47 and .cpp:38-39, evaluated on the host in the reference's expression order
@@ -820,8 +814,11 @@ int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const in
     K.min_az = min_az;
     K.width = int(round(360 / cfg.deltaP));
     K.height = int(((max_az - min_az) * 180 / M_PI) / cfg.deltaA) + 1;
-    hipLaunchKernelGGL(cluster_class_kernel, dim3(kNumFgClasses), dim3(kBlock), 0, s, in, g.params, g.fg_order, K, g.cell3,
-                       g.cell_pts, reinterpret_cast<int32_t *>(g.table), g.label, g.parent, g.stat, g.pt_cluster);
+    hipLaunchKernelGGL(route_totals_kernel, dim3(1), dim3(kBlock), 0, s, g.cat_blockcnt, nb, g.counts, g.params, g.range_ext);
+    hipLaunchKernelGGL(route_scatter_kernel, dim3(nb), dim3(kBlock), 0, s, in, n_ptr, g.cat_blockcnt, g.params, K, g.fg_order,
+                       g.fg_all, g.bg_all, g.pol_azi, g.apr_range, g.range_ext);
+    hipLaunchKernelGGL(cluster_class_kernel, dim3(kNumFgClasses), dim3(kBlock), 0, s, in, g.params, g.fg_order, g.pol_azi,
+                       g.apr_range, g.range_ext, K, g.cslot, g.plabel, g.table, g.parent, g.stat, g.pt_cluster);
     char *hb = g.hostblk_dev;
     hipLaunchKernelGGL(cluster_boxes_kernel, dim3(1), dim3(kBlock), 0, s, g.params, g.counts, g.stat,
                        reinterpret_cast<GraphHostHeader *>(hb), reinterpret_cast<ClusterRec *>(hb + kHbRecs), kMaxClusters,

@@ -22,10 +22,6 @@ struct ClassParams {
     double min_range, max_range;
 };
 
-struct CellSlot {  // 16 bytes of global scratch per slot: three int32 planes (key / list end / count) are carved from it
-    int32_t w[4];
-};
-
 struct ClusterStat {
     unsigned long long lo[3], hi[3];  // order-preserving encodings of the AABB doubles
     int32_t count, first;             // points, smallest class-local point index
@@ -39,14 +35,15 @@ struct GraphScratch {
     int32_t *bg_all = nullptr;        // background points in original order
     int32_t *counts = nullptr;        // [8]: per class n (5), n_fg, n_bg
     ClassParams *params = nullptr;    // [5]
-    int32_t *cell3 = nullptr;         // [N][4]: polar, range, azimuth cell coordinates per fg point (class order)
-    int32_t *cell_pts = nullptr;      // [N]
-    CellSlot *table = nullptr;        // [4N]
-    int32_t *label = nullptr;         // [N] cluster label per fg point (class order)
+    int32_t *pol_azi = nullptr;       // [N][2]: polar / azimuth cell coordinates per fg point (class order)
+    double *apr_range = nullptr;      // [N] planar range per fg point (class order)
+    unsigned long long *range_ext = nullptr;  // [5][2] order-preserving encodings of each class' min / max range
+    int32_t *cslot = nullptr;         // [N] cell-table slot per fg point (classes too large for LDS only)
+    int32_t *plabel = nullptr;        // [N] per-point labels of cells outside every neighbour list (same)
+    int32_t *table = nullptr;         // [32N] cell tables of the classes too large for LDS (8 planes x cap <= 4n)
     int32_t *parent = nullptr;        // [N + 8] union-find over label values (per class slice, offset by start + class)
     ClusterStat *stat = nullptr;      // [N + 8]
     int32_t *pt_cluster = nullptr;    // [N] final cluster id per ORIGINAL point (0 = not foreground)
-    double *apr_range = nullptr;      // [N]
     // graph
     double *boxes_dev = nullptr;      // [kMaxNodes][8]
     double *edge_dev = nullptr;       // [kMaxNodes^2]

@@ -294,7 +294,7 @@ def test_register_frame_matches_oracle():
 
 
 # ---------------- SemanticCluster / SemGraph ----------------
-@pytest.mark.parametrize("shape,frame", [("small", 3), ("small", 25), ("hdl64", 12)])
+@pytest.mark.parametrize("shape,frame", [("small", 3), ("small", 25), ("hdl64", 12), ("os1_64", 7), ("hdl64", 60)])
 def test_cluster_points_match_oracle(ctx_small, shape, frame):
     _, xyz, lab = _scan(frame, shape)
     px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
@@ -320,6 +320,18 @@ def test_cluster_edge_cases(ctx_small):
     lab = np.full(80, 16, dtype=np.int32)
     bo, pco, _, _ = O.cluster_points(blob, lab, 2.0, 0.5, 2.0)
     bg, pcg, _, _ = ctx_small.ClusterPoints(blob, lab, 2.0, 0.5, 2.0)
+    assert np.array_equal(pco, pcg) and np.array_equal(bo, bg)
+    # a column of points crossing the +2 deg elevation limit: cells above it are in nobody's neighbour list
+    col = np.stack([10 + RNG.normal(size=600) * 0.4, RNG.normal(size=600) * 0.4, RNG.uniform(-1.5, 3.0, size=600)], axis=1)
+    lab = np.full(600, 18, dtype=np.int32)
+    bo, pco, _, _ = O.cluster_points(col, lab, 2.0, 0.5, 2.0)
+    bg, pcg, _, _ = ctx_small.ClusterPoints(col, lab, 2.0, 0.5, 2.0)
+    assert np.array_equal(pco, pcg) and np.array_equal(bo, bg)
+    # one class too large for the LDS working set (global-scratch path of the same kernel)
+    big = RNG.normal(size=(9000, 3)) * [12, 12, 0.8] + [0, 0, -0.5]
+    lab = np.full(9000, 1, dtype=np.int32)
+    bo, pco, _, _ = O.cluster_points(big, lab, 2.0, 0.5, 2.0)
+    bg, pcg, _, _ = ctx_small.ClusterPoints(big, lab, 2.0, 0.5, 2.0)
     assert np.array_equal(pco, pcg) and np.array_equal(bo, bg)
     # random multi-class soup against the oracle
     xyz = RNG.normal(size=(4000, 3)) * [15, 15, 1.0] + [0, 0, -0.5]
