@@ -296,6 +296,7 @@ __device__ inline int block_excl_scan(int v, int *wsum /*shared [kBlock/64]*/, i
 // included, so it is never swept: each of its points is a seed that is labelled alone.
 // What stays serial is one step per seed, on wave 0: lanes 0..26 hold the 27 neighbour cells.
 constexpr int kLdsWords = 36 * 1024;  // 144 KiB of the CU's 160 KiB
+constexpr int kCluThreads = 1024;     // build / neighbour lists / statistics are parallel; the walk uses wave 0
 struct ClusterMem {
     int32_t *cslot;   // [n] table slot of every point's cell
     int32_t *plabel;  // [n] label of a point whose cell no neighbour list contains (see walk), else unused
@@ -348,11 +349,11 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
         params[c].length = length; params[c].width = width; params[c].height = height;
         s_ncells = 0;
     }
-    for (int s = tid; s < cap; s += kBlock) { M.tkey[s] = INT_MIN; M.tmin[s] = INT_MAX; M.tlab[s] = -1; M.tswept[s] = 0; }
+    for (int s = tid; s < cap; s += kCluThreads) { M.tkey[s] = INT_MIN; M.tmin[s] = INT_MAX; M.tlab[s] = -1; M.tswept[s] = 0; }
     __syncthreads();
 
     // ---- B: cell of every point (:50-54) -> cell table (key, smallest point index, coordinates)
-    for (int j = tid; j < n; j += kBlock) {
+    for (int j = tid; j < n; j += kCluThreads) {
         const int pol = pol_azi[2 * (size_t)j], azi = pol_azi[2 * (size_t)j + 1];
         const int rng = (int)((apr_range[j] - minR) / K.dR);
         const int vidx = (pol * length + rng) + azi * length * width;
@@ -361,7 +362,9 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
             const int cur = atomicCAS(&M.tkey[s], INT_MIN, vidx);
             if (cur == INT_MIN) {  // this thread created the cell
                 M.tpol[s] = pol; M.trng[s] = rng; M.tazi[s] = azi;
-                M.tcidx[s] = atomicAdd(&s_ncells, 1);
+                const int ci = atomicAdd(&s_ncells, 1);
+                M.tcidx[s] = ci;
+                M.plabel[ci] = (int)s;  // dense list of the occupied slots (plabel is not in use before the walk)
                 break;
             }
             if (cur == vidx) break;
@@ -374,9 +377,10 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
     // ---- C: neighbour lists of the occupied cells (27 lookups each), when they fit
     const bool lists = M.nbr != nullptr && s_ncells <= M.nbr_cells;
     if (lists) {
-        for (int e = tid; e < 27 * cap; e += kBlock) {
-            const int s = e / 27, k = e - 27 * s;
-            if (M.tkey[s] != INT_MIN) M.nbr[27 * M.tcidx[s] + k] = neighbour_slot(M, s, k, length, width, height);
+        const int pairs = 27 * s_ncells;
+        for (int e = tid; e < pairs; e += kCluThreads) {
+            const int ci = e / 27, k = e - 27 * ci;
+            M.nbr[e] = neighbour_slot(M, M.plabel[ci], k, length, width, height);
         }
     }
     __syncthreads();
@@ -395,7 +399,7 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
                 const int fl0 = __ffsll((long long)um) - 1;
                 const int i = base + fl0;  // next unlabelled point = seed
                 last = i;
-                const int own = __shfl(sl, fl0);
+                const int own = __builtin_amdgcn_readlane(sl, fl0);
                 int ns = -1;
                 if (lane < 27) ns = lists ? M.nbr[27 * M.tcidx[own] + lane] : neighbour_slot(M, own, lane, length, width, height);
                 const bool exist = ns >= 0;
@@ -453,7 +457,7 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
     // accumulators sit in LDS (the neighbour lists' words, free now) unless there are too many clusters.
     const int current = s_current;
     ClusterStat *const acc = (LDS && current <= stat_lds_cap) ? stat_lds : stat_out;  // generic pointer: flat atomics
-    for (int v = 1 + tid; v <= current; v += kBlock) {
+    for (int v = 1 + tid; v <= current; v += kCluThreads) {
         ClusterStat e;
         e.lo[0] = e.lo[1] = e.lo[2] = ~0ull;
         e.hi[0] = e.hi[1] = e.hi[2] = 0ull;
@@ -462,7 +466,7 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
         acc[v] = e;
     }
     __syncthreads();
-    for (int j = tid; j < n; j += kBlock) {
+    for (int j = tid; j < n; j += kCluThreads) {
         const int sl = cslot[j];
         const int v = find_root(parent, M.tswept[sl] == 2 ? M.plabel[j] : M.tlab[sl]);
         const int oi = order[j];
@@ -477,12 +481,12 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
     }
     if (acc != stat_out) {
         __syncthreads();
-        for (int v = 1 + tid; v <= current; v += kBlock) stat_out[v] = acc[v];
+        for (int v = 1 + tid; v <= current; v += kCluThreads) stat_out[v] = acc[v];
     }
 }
 
 // one workgroup per class; the working set lives in LDS when the class fits, else in global scratch
-__global__ __launch_bounds__(kBlock) void cluster_class_kernel(CloudView in, ClassParams *params,
+__global__ __launch_bounds__(kCluThreads) void cluster_class_kernel(CloudView in, ClassParams *params,
                                                                const int32_t *__restrict__ fg_order,
                                                                const int32_t *__restrict__ pol_azi,
                                                                const double *__restrict__ apr_range,
@@ -817,7 +821,7 @@ int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const in
     hipLaunchKernelGGL(route_totals_kernel, dim3(1), dim3(kBlock), 0, s, g.cat_blockcnt, nb, g.counts, g.params, g.range_ext);
     hipLaunchKernelGGL(route_scatter_kernel, dim3(nb), dim3(kBlock), 0, s, in, n_ptr, g.cat_blockcnt, g.params, K, g.fg_order,
                        g.fg_all, g.bg_all, g.pol_azi, g.apr_range, g.range_ext);
-    hipLaunchKernelGGL(cluster_class_kernel, dim3(kNumFgClasses), dim3(kBlock), 0, s, in, g.params, g.fg_order, g.pol_azi,
+    hipLaunchKernelGGL(cluster_class_kernel, dim3(kNumFgClasses), dim3(kCluThreads), 0, s, in, g.params, g.fg_order, g.pol_azi,
                        g.apr_range, g.range_ext, K, g.cslot, g.plabel, g.table, g.parent, g.stat, g.pt_cluster);
     char *hb = g.hostblk_dev;
     hipLaunchKernelGGL(cluster_boxes_kernel, dim3(1), dim3(kBlock), 0, s, g.params, g.counts, g.stat,
