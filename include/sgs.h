@@ -67,6 +67,12 @@ typedef struct sgs_config {
     int32_t max_points;        /* largest scan accepted (default 1<<20) */
     int32_t map_capacity_log2; /* voxel hash slots = 1<<this (default 19); grows by rehash */
     int32_t enable_graph;      /* run clustering + graph construction in sgs_process_scan */
+    int32_t async_map_update;  /* 0 (default): sgs_process_scan* returns after the local-map update of the scan.
+                                  1: it returns as soon as the pose is known; the map update stays queued on the
+                                  device and overlaps the caller's next call.  Poses, clouds and the graph are the
+                                  same; sgs_scan_result.map_voxels then counts the map the scan was registered
+                                  AGAINST (one update behind); every other entry point first waits for the update. */
+    int32_t reserved0;
 } sgs_config;
 
 typedef struct sgs_ctx sgs_ctx;
@@ -80,7 +86,7 @@ typedef struct sgs_scan_result {
     double sigma;           /* adaptive threshold used for this scan */
     int32_t n_raw, n_in, n_cluster, n_ds, n_src; /* cloud sizes after each stage */
     int32_t n_boxes;        /* instance nodes found (0 when enable_graph == 0) */
-    int32_t map_voxels;     /* live voxels after the update */
+    int32_t map_voxels;     /* live voxels after the update (async_map_update: before it) */
     int32_t reserved;
     int64_t icp_correspondences; /* summed over iterations */
     int64_t icp_candidates;      /* candidate map points examined, summed over iterations */

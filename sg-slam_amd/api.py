@@ -46,6 +46,7 @@ class SgsConfig(ctypes.Structure):
         ("nearest_neighbor_vehicle_disth", c_dbl), ("nearest_neighbor_pole_disth", c_dbl),
         ("max_local_graph_map_range", c_dbl),
         ("order_mode", i32), ("max_points", i32), ("map_capacity_log2", i32), ("enable_graph", i32),
+        ("async_map_update", i32), ("reserved0", i32),
     ]
 
 

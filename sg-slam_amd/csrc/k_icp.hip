@@ -353,9 +353,9 @@ __device__ inline void wave_solve6(SolveLds &L, int lane) {
 }
 
 // 6x6 solve + SE3 update + convergence test of one Gauss-Newton iteration (F/Registration.cpp:
-// 111-112,165-172), run by wave 0 of the folding block.  mailbox: 4 ints in host-pinned,
-// device-mapped memory {iterations finished, done, -, -}; the host polls it instead of a copy +
-// stream sync.
+// 111-112,165-172), run by wave 0 of the folding block.  The host polls mirror->icp_iter / icp_done
+// (host-pinned, device-mapped) instead of a copy + stream sync; when the loop ends the pose, cloud
+// sizes and counters of the scan are left there too.
 struct TailState {  // what the solve tail reads from DevState, fetched before the fold so the loads overlap it
     Rigid T_icp, T_total;
     long long corr, cand, probe;
@@ -366,7 +366,7 @@ __device__ inline TailState load_tail_state(const DevState *st) {
 }
 
 __device__ inline void solve_and_update(DevState *st, const TailState &ts, const double *S, SolveLds &L, int lane,
-                                        int32_t *mailbox) {
+                                        HostMirror *mirror) {
     if (lane == 0) {
         double b[6];
         normal_equations(S, L.A, b);
@@ -380,30 +380,42 @@ __device__ inline void solve_and_update(DevState *st, const TailState &ts, const
     double x[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) x[i] = L.x[i];
-    // lane 0: T_icp <- est * T_icp; lane 1: T_total <- est * T_total (= T_icp_new * guess), side by side
-    const Rigid est = rigid_exp_small(D3{x[0], x[1], x[2]}, D3{x[3], x[4], x[5]});
-    const Rigid upd = compose_fast(est, lane == 0 ? ts.T_icp : ts.T_total);
-    if (lane == 1) {
-        st->T_total = upd;
-        return;
-    }
-    st->T_icp = upd;
-    st->icp_corr = ts.corr + (long long)S[16];
-    st->icp_cand = ts.cand + (long long)S[17];
-    st->icp_probe = ts.probe + (long long)S[18];
-    const int it = ts.iter + 1;
-    st->icp_iter = it;
     // estimation.log().norm() < 1e-4 (F/Registration.cpp:169): log(exp(x)) == x for |omega| < pi, so
     // the squared 6-vector norm of the update itself is compared with 1e-8
     double nn = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
+    const int it = ts.iter + 1;
     const int done = (nn < 1e-8 || it >= ts.max_iter) ? 1 : 0;
+    // lane 0: T_icp <- est * T_icp; lane 1: T_total <- est * T_total (= T_icp_new * guess), side by side
+    const Rigid est = rigid_exp_small(D3{x[0], x[1], x[2]}, D3{x[3], x[4], x[5]});
+    const Rigid upd = compose_fast(est, lane == 0 ? ts.T_icp : ts.T_total);
+    // lane 1's result for lane 0, which publishes it to the host below (one lane does all host-visible
+    // stores, so its release orders them)
+    const double tq[7] = {bcast_lane<1>(upd.qw), bcast_lane<1>(upd.qx), bcast_lane<1>(upd.qy), bcast_lane<1>(upd.qz),
+                          bcast_lane<1>(upd.t.x), bcast_lane<1>(upd.t.y), bcast_lane<1>(upd.t.z)};
+    if (lane == 1) {
+        st->T_total = upd;
+        return;
+    }
+    st->T_icp = upd;
+    const long long corr = ts.corr + (long long)S[16], cand = ts.cand + (long long)S[17], probe = ts.probe + (long long)S[18];
+    st->icp_corr = corr;
+    st->icp_cand = cand;
+    st->icp_probe = probe;
+    st->icp_iter = it;
     if (done) st->icp_done = 1;
     st->icp_ticket = 0;
-    if (mailbox) {
-        __hip_atomic_store(&mailbox[0], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mailbox[1], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (mirror) {
+        if (done) {  // everything the host wants to know about this scan before the map update
+            mirror->n_in = st->n_in; mirror->n_c = st->n_c; mirror->n_d = st->n_d; mirror->n_s = st->n_s;
+            mirror->err_flags = st->err_flags;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) mirror->pose[k] = tq[k];
+            mirror->icp_corr = corr; mirror->icp_cand = cand; mirror->icp_probe = probe;
+        }
+        __hip_atomic_store(&mirror->icp_iter, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mirror->icp_done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -417,7 +429,7 @@ __device__ inline void solve_and_update(DevState *st, const TailState &ts, const
 // +29 us per launch.
 __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, CloudView src, int src_cap,
                                                                     const int32_t *__restrict__ n_ptr, DevState *st,
-                                                                    double *partials, int fuse, int32_t *mailbox) {
+                                                                    double *partials, int fuse, HostMirror *mirror) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int waves_per_block = kIcpThreads / 64;
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
     TailState ts{};
     if (wave == 0) ts = load_tail_state(st);
     fold_partials<kIcpThreads / 64>(partials, S);
-    if (wave == 0) solve_and_update(st, ts, S, solve_lds, lane, mailbox);
+    if (wave == 0) solve_and_update(st, ts, S, solve_lds, lane, mirror);
 }
 
 __global__ __launch_bounds__(256) void icp_finish_kernel(DevState *st, const double *partials, int nblocks,
@@ -556,9 +568,9 @@ void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max
 }
 
 void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
-                          double *partials, bool solve, int32_t *mailbox) {
+                          double *partials, bool solve, HostMirror *mirror) {
     hipLaunchKernelGGL(icp_iteration_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st,
-                       partials, solve ? 1 : 0, mailbox);
+                       partials, solve ? 1 : 0, mirror);
 }
 
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out28_dev) {

@@ -150,7 +150,8 @@ __global__ __launch_bounds__(kBlock) void map_prune_kernel(MapView m, const Rigi
                                           red[2][0] + red[2][1] + red[2][2] + red[2][3], 0);
 }
 
-__global__ __launch_bounds__(kBlock) void map_census_kernel(const int4 *__restrict__ blockstat, int nblocks, DevState *st) {
+__global__ __launch_bounds__(kBlock) void map_census_kernel(const int4 *__restrict__ blockstat, int nblocks, DevState *st,
+                                                            HostMirror *mirror) {
     int live = 0, tomb = 0, pts = 0;
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
         const int4 v = blockstat[b];
@@ -168,9 +169,18 @@ __global__ __launch_bounds__(kBlock) void map_census_kernel(const int4 *__restri
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        st->map_live = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        st->map_tomb = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        st->map_points = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        const int l = red[0][0] + red[0][1] + red[0][2] + red[0][3], t = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const int p = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        st->map_live = l;
+        st->map_tomb = t;
+        st->map_points = p;
+        if (mirror) {
+            mirror->map_live = l;
+            mirror->map_tomb = t;
+            mirror->map_points = p;
+            mirror->map_err_flags = st->err_flags;
+            __hip_atomic_store(&mirror->census_seq, mirror->census_seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -217,14 +227,14 @@ void launch_map_add(hipStream_t s, MapView m, CloudView in, const int32_t *n_ptr
 }
 
 void launch_map_sweep(hipStream_t s, MapView m, const Rigid *T_dev, const double *origin3_host, double max_dist,
-                      int do_prune, int4 *blockstat, DevState *st) {
+                      int do_prune, int4 *blockstat, DevState *st, HostMirror *mirror) {
     const uint32_t cap = m.mask + 1u;
     D3 o{0, 0, 0};
     if (origin3_host) o = D3{origin3_host[0], origin3_host[1], origin3_host[2]};
     const int nb = (int)((cap + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(map_prune_kernel, dim3(nb), dim3(kBlock), 0, s, m, T_dev, o, max_dist * max_dist, do_prune,
                        blockstat);
-    hipLaunchKernelGGL(map_census_kernel, dim3(1), dim3(kBlock), 0, s, blockstat, nb, st);
+    hipLaunchKernelGGL(map_census_kernel, dim3(1), dim3(kBlock), 0, s, blockstat, nb, st, mirror);
 }
 
 void launch_map_rehash(hipStream_t s, MapView from, MapView to, DevState *st) {

@@ -103,8 +103,9 @@ struct sgs_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // instance clustering + graph run here, concurrently with the ICP loop
     hipEvent_t ev_ds = nullptr, ev_g0 = nullptr, ev_g1 = nullptr;
-    int32_t *mailbox = nullptr;      // host-pinned, device-mapped: {icp iterations finished, done}
-    int32_t *mailbox_dev = nullptr;
+    HostMirror *mirror = nullptr;    // host-pinned, device-mapped: ICP progress, pose / sizes of the scan, map census
+    HostMirror *mirror_dev = nullptr;
+    bool async_pending = false;      // a map update of sgs_process_scan is still queued (cfg.async_map_update)
     std::string err;
     std::vector<void *> allocs;
     int N = 0;  // max points per scan
@@ -235,11 +236,11 @@ int sync_state(sgs_ctx *c) {
     c->map_live_host = c->st_host->map_live;
     c->map_tomb_host = c->st_host->map_tomb;
     c->map_points_host = c->st_host->map_points;
+    c->async_pending = false;
     return SGS_OK;
 }
 
-int check_err_flags(sgs_ctx *c) {
-    const int f = c->st_host->err_flags;
+int check_err_flags(sgs_ctx *c, int f) {
     if (!f) return SGS_OK;
     hipMemsetAsync(&c->st->err_flags, 0, sizeof(int32_t), c->stream);
     if (f & ERR_MAP_FULL) return fail(c, SGS_ECAPACITY, "voxel map table full");
@@ -371,10 +372,10 @@ int enqueue_icp_iteration(sgs_ctx *c, CloudView src, const int32_t *n_ptr) {
         }
         auto &ev = c->icp_events[c->icp_events_used++];
         SGS_HIP(c, hipEventRecord(ev.first, c->stream));
-        launch_icp_iteration(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, true, c->mailbox_dev);
+        launch_icp_iteration(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, true, c->mirror_dev);
         SGS_HIP(c, hipEventRecord(ev.second, c->stream));
     } else {
-        launch_icp_iteration(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, true, c->mailbox_dev);
+        launch_icp_iteration(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, true, c->mirror_dev);
     }
     return SGS_OK;
 }
@@ -384,7 +385,7 @@ int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const Rigid &guess,
     launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, 0);
     *iters_out = 0;
     if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
-    volatile int32_t *mb = c->mailbox;
+    volatile int32_t *mb = &c->mirror->icp_iter;  // [0] iterations finished, [1] done
     mb[0] = 0;
     mb[1] = 0;
     __sync_synchronize();
@@ -501,15 +502,36 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     if (r) return r;
     if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[3], s);
     // ---- local map update with the new pose, still on the device (P/SemGraphSLAM.cpp:113)
+    // cfg.async_map_update: the update is only ENQUEUED here; everything the caller gets back was left
+    // in the host mirror by the kernel that ended the ICP loop, so the call returns while the update
+    // runs and the next scan's preprocessing is queued behind it (same stream, so the next ICP sees the
+    // updated map).  Needs an ICP loop that ran (not the first scan of a sequence).
+    const bool async = cfg.async_map_update != 0 && iters > 0 && !c->profiling;
+    DevState hs;  // host view of the device state for this scan
+    if (async) {
+        const HostMirror &mi = *c->mirror;
+        // the census of the previous update finished before this scan's ICP could start
+        c->map_live_host = mi.map_live; c->map_tomb_host = mi.map_tomb; c->map_points_host = mi.map_points;
+        hs.n_in = mi.n_in; hs.n_c = mi.n_c; hs.n_d = mi.n_d; hs.n_s = mi.n_s;
+        hs.err_flags = mi.err_flags | mi.map_err_flags;
+        hs.T_total = Rigid{mi.pose[0], mi.pose[1], mi.pose[2], mi.pose[3], D3{mi.pose[4], mi.pose[5], mi.pose[6]}};
+        hs.icp_corr = mi.icp_corr; hs.icp_cand = mi.icp_cand; hs.icp_probe = mi.icp_probe;
+        hs.map_live = mi.map_live;  // voxels of the map this scan was registered against
+    }
     r = maybe_rehash(c, n);
     if (r) return r;
     launch_map_add(s, c->map.v, c->ds, &c->st->n_d, n, &c->st->T_total, c->map_slot_of, c->map_next, c->world, c->st);
-    launch_map_sweep(s, c->map.v, &c->st->T_total, nullptr, cfg.max_range, 1, c->map_blockstat, c->st);
+    launch_map_sweep(s, c->map.v, &c->st->T_total, nullptr, cfg.max_range, 1, c->map_blockstat, c->st, c->mirror_dev);
     if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[4], s);
     // ---- collect the clusters, emit boxes in the reference's order, build the graph (P/SemGraphSLAM.cpp:44-51)
     int n_boxes = 0;
-    r = sync_state(c);
-    if (r) return r;
+    if (async) {
+        c->async_pending = true;
+    } else {
+        r = sync_state(c);
+        if (r) return r;
+        hs = *c->st_host;
+    }
     if (cfg.enable_graph) {
         guard.armed = false;
         r = c->gworker.wait();
@@ -519,9 +541,9 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
         }
         n_boxes = c->job_n_boxes;
     }
-    r = check_err_flags(c);
+    r = check_err_flags(c, hs.err_flags);
     if (r) return r;
-    const DevState &h = *c->st_host;
+    const DevState &h = hs;
     const Rigid new_pose = h.T_total;
     // ---- model deviation / pose list (P/SemGraphSLAM.cpp:79,110,119)
     c->model_deviation = compose(invert(guess), new_pose);
@@ -581,6 +603,7 @@ void sgs_default_config(sgs_config *cfg) {
     cfg->nearest_neighbor_vehicle_disth = 1.0; cfg->nearest_neighbor_pole_disth = 1.0;
     cfg->max_local_graph_map_range = 60.0;
     cfg->order_mode = 0; cfg->max_points = 1 << 20; cfg->map_capacity_log2 = 19; cfg->enable_graph = 1;
+    cfg->async_map_update = 0; cfg->reserved0 = 0;
 }
 
 int sgs_preset(const char *name, sgs_config *cfg) {
@@ -645,9 +668,9 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     if (hipEventCreateWithFlags(&c->ev_ds, hipEventDisableTiming) != hipSuccess || hipEventCreate(&c->ev_g0) != hipSuccess ||
         hipEventCreate(&c->ev_g1) != hipSuccess)
         return bail(SGS_EHIP);
-    if (hipHostMalloc((void **)&c->mailbox, 64, hipHostMallocMapped) != hipSuccess) return bail(SGS_ENOMEM);
-    if (hipHostGetDevicePointer((void **)&c->mailbox_dev, c->mailbox, 0) != hipSuccess) return bail(SGS_EHIP);
-    memset(c->mailbox, 0, 64);
+    if (hipHostMalloc((void **)&c->mirror, sizeof(HostMirror), hipHostMallocMapped) != hipSuccess) return bail(SGS_ENOMEM);
+    if (hipHostGetDevicePointer((void **)&c->mirror_dev, c->mirror, 0) != hipSuccess) return bail(SGS_EHIP);
+    memset(c->mirror, 0, sizeof(HostMirror));
     if ((r = dev_alloc(c, &c->in_f32, N * 4))) return bail(r);
     if ((r = dev_alloc(c, &c->in_f64, N * 3))) return bail(r);
     if ((r = dev_alloc(c, &c->in_label, N))) return bail(r);
@@ -700,7 +723,7 @@ void sgs_destroy(sgs_ctx *c) {
     if (c->ev_ds) hipEventDestroy(c->ev_ds);
     if (c->ev_g0) hipEventDestroy(c->ev_g0);
     if (c->ev_g1) hipEventDestroy(c->ev_g1);
-    if (c->mailbox) hipHostFree(c->mailbox);
+    if (c->mirror) hipHostFree(c->mirror);
     if (c->stream2) hipStreamDestroy(c->stream2);
     for (void *p : c->allocs) hipFree(p);
     free_map(&c->map);
@@ -737,9 +760,16 @@ int sgs_set_profiling(sgs_ctx *c, int enable) {
     return SGS_OK;
 }
 
-#define ENTER(c)                          \
+#define ENTER_NOSETTLE(c)                 \
     if (bad_ctx(c)) return SGS_EINVAL;    \
     if (hipSetDevice((c)->device) != hipSuccess) return fail((c), SGS_EHIP, "hipSetDevice failed")
+// every entry point except sgs_process_scan* first waits for a map update still queued by it
+#define ENTER(c)                          \
+    ENTER_NOSETTLE(c);                    \
+    if ((c)->async_pending) {             \
+        const int rs_ = sync_state(c);    \
+        if (rs_) return rs_;              \
+    }
 #define CHECK_N(c, n) \
     if ((n) < 0 || (n) > (c)->N) return fail((c), (n) < 0 ? SGS_EINVAL : SGS_ECAPACITY, "n=%d outside [0, max_points=%d]", (n), (c)->N)
 
@@ -813,7 +843,7 @@ int sgs_voxel_downsample(sgs_ctx *c, const double *xyz, const int32_t *label, in
     if (n == 0) { *out_n = 0; return SGS_OK; }
     if ((r = read_dev_int(c, &c->aux_n[1], &m))) return r;
     if ((r = sync_state(c))) return r;
-    if ((r = check_err_flags(c))) return r;
+    if ((r = check_err_flags(c, c->st_host->err_flags))) return r;
     *out_n = m;
     const int k = std::min(m, out_cap);
     if ((r = download_cloud(c, c->aux, k, out_xyz, out_label))) return r;
@@ -846,9 +876,9 @@ static int map_add_common(sgs_ctx *c, const double *xyzl, int n, const double *p
         T_dev = &c->st->T_total;
     }
     launch_map_add(c->stream, c->map.v, c->aux, &c->aux_n[0], n, T_dev, c->map_slot_of, c->map_next, c->world, c->st);
-    launch_map_sweep(c->stream, c->map.v, T_dev, nullptr, c->cfg.max_range, prune ? 1 : 0, c->map_blockstat, c->st);
+    launch_map_sweep(c->stream, c->map.v, T_dev, nullptr, c->cfg.max_range, prune ? 1 : 0, c->map_blockstat, c->st, c->mirror_dev);
     if ((r = sync_state(c))) return r;
-    return check_err_flags(c);
+    return check_err_flags(c, c->st_host->err_flags);
 }
 int sgs_map_add_points(sgs_ctx *c, const double *xyzl, int n) {
     ENTER(c);
@@ -865,7 +895,7 @@ int sgs_map_update(sgs_ctx *c, const double *xyzl, int n, const double *pose7) {
 int sgs_map_prune(sgs_ctx *c, const double *origin3) {
     ENTER(c);
     if (!origin3) return fail(c, SGS_EINVAL, "null argument");
-    launch_map_sweep(c->stream, c->map.v, nullptr, origin3, c->cfg.max_range, 1, c->map_blockstat, c->st);
+    launch_map_sweep(c->stream, c->map.v, nullptr, origin3, c->cfg.max_range, 1, c->map_blockstat, c->st, c->mirror_dev);
     return sync_state(c);
 }
 int sgs_map_size(sgs_ctx *c, int *voxels, int *points) {
@@ -1036,7 +1066,7 @@ int sgs_build_graph(sgs_ctx *c, const double *boxes, int nb, double edge_dis_th,
 // ---- pipeline ----
 int sgs_process_scan(sgs_ctx *c, const double *xyz, const int32_t *label, int n, const double *ts, int is_kitti,
                      sgs_scan_result *res) {
-    ENTER(c);
+    ENTER_NOSETTLE(c);
     CHECK_N(c, n);
     if (n && (!xyz || !label)) return fail(c, SGS_EINVAL, "null argument");
     SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -1046,7 +1076,7 @@ int sgs_process_scan(sgs_ctx *c, const double *xyz, const int32_t *label, int n,
 }
 int sgs_process_scan_f32(sgs_ctx *c, const float *xyzi, const int32_t *label, int n, const double *ts, int is_kitti,
                          sgs_scan_result *res) {
-    ENTER(c);
+    ENTER_NOSETTLE(c);
     CHECK_N(c, n);
     if (n && (!xyzi || !label)) return fail(c, SGS_EINVAL, "null argument");
     SGS_HIP(c, hipMemcpyAsync(c->in_f32, xyzi, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -1056,7 +1086,7 @@ int sgs_process_scan_f32(sgs_ctx *c, const float *xyzi, const int32_t *label, in
 }
 int sgs_process_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *label_dev, int n, const double *ts_dev,
                              int is_kitti, sgs_scan_result *res) {
-    ENTER(c);
+    ENTER_NOSETTLE(c);
     CHECK_N(c, n);
     if (n && (!xyzi_dev || !label_dev)) return fail(c, SGS_EINVAL, "null argument");
     return process_scan_dev(c, xyzi_dev, nullptr, label_dev, n, ts_dev, is_kitti, res);

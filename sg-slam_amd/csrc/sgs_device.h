@@ -78,6 +78,19 @@ struct DevState {
 
 enum { ERR_KEY_RANGE = 1, ERR_MAP_FULL = 2, ERR_SCAN_TOO_LARGE = 4 };
 
+// Host-pinned, device-mapped mirror of the few DevState words the host needs while kernels are still
+// queued: the kernels write it with system-scope stores, the host polls / reads it without a copy or
+// a stream synchronisation.
+struct HostMirror {
+    int32_t icp_iter, icp_done;    // Gauss-Newton iterations finished / loop ended (polled during the loop)
+    int32_t n_in, n_c, n_d, n_s;   // cloud sizes of the scan, copied when the loop ends
+    int32_t err_flags, pad0;       // DevState::err_flags at that moment
+    double pose[7];                // T_total as qw, qx, qy, qz, tx, ty, tz, written when the loop ends
+    long long icp_corr, icp_cand, icp_probe;
+    int32_t map_live, map_tomb, map_points, map_err_flags;  // written by every map sweep (census)
+    int32_t census_seq, pad1;
+};
+
 // ---- k_pre.hip ----
 struct PreParams {
     int mode_kitti;   // apply CorrectKITTIScan
@@ -104,7 +117,7 @@ void launch_map_add(hipStream_t s, MapView m, CloudView in, const int32_t *n_ptr
                     DevState *st);
 // sweep = optional prune (origin = T_dev->t when T_dev != nullptr, else origin3_host) + census into st
 void launch_map_sweep(hipStream_t s, MapView m, const Rigid *T_dev, const double *origin3_host, double max_dist,
-                      int do_prune, int4 *blockstat, DevState *st);
+                      int do_prune, int4 *blockstat, DevState *st, HostMirror *mirror /*host-mapped, nullable*/);
 void launch_map_rehash(hipStream_t s, MapView from, MapView to, DevState *st);
 void launch_map_clear(hipStream_t s, MapView m, DevState *st);
 
@@ -117,7 +130,7 @@ void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max
 // launch_linear_system_finish.
 void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap /*elements allocated, >= 1*/,
                           const int32_t *n_ptr, DevState *st, double *partials, bool solve,
-                          int32_t *mailbox /*host-mapped, nullable*/);
+                          HostMirror *mirror /*host-mapped, nullable*/);
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
                             int32_t *found);
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out27_dev);

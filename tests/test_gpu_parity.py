@@ -420,6 +420,32 @@ def test_pipeline_deskew_mulran_shape():
     _run_pipeline("small", 10, deskew=1)
 
 
+def test_pipeline_async_map_update_matches_sync():
+    """cfg.async_map_update only moves the host's wait: poses, clouds, boxes and the final map are
+    bit-identical to the synchronous run; map_voxels is reported one update behind."""
+    a, b = make_ctx(async_map_update=1), make_ctx()
+    prev_voxels = None
+    for k in range(25):
+        xyzi, xyz, lab = _scan(k, "small")
+        ra, rb = a.process_scan_f32(xyzi, lab, None, ""), b.process_scan_f32(xyzi, lab, None, "")
+        assert np.array_equal(ra["pose"], rb["pose"]) and ra["iterations"] == rb["iterations"]
+        for f in ("n_in", "n_cluster", "n_ds", "n_src", "n_boxes", "correspondences", "candidates"):
+            assert ra[f] == rb[f], (k, f)
+        assert ra["map_voxels"] == (rb["map_voxels"] if ra["iterations"] == 0 else prev_voxels)
+        prev_voxels = rb["map_voxels"]
+        if k % 6 == 0:
+            assert np.array_equal(a.boxes(), b.boxes())
+            for which in (1, 3):
+                assert np.array_equal(a.cloud(which)[0], b.cloud(which)[0])
+    assert a.map_size() == b.map_size()  # any other entry point waits for the queued update
+    ka, ca, pa = a.map_dump()
+    kb, cb, pb = b.map_dump()
+    assert np.array_equal(ka, kb) and np.array_equal(ca, cb) and np.array_equal(pa, pb)
+    assert np.array_equal(a.poses(), b.poses())
+    a.close()
+    b.close()
+
+
 def test_error_behaviour():
     ctx = make_ctx(max_points=1024)
     big = np.zeros((2000, 3))
