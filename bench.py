@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip instance clustering + graph (diagnostic only)")
     ap.add_argument("--cpu-max-scans", type=int, default=120)
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not hand scan k+1 to sgs_prefetch_scan_f32_dev while scan k registers (default: do; the "
+                         "front half of the next scan then overlaps the ICP of the current one)")
     ap.add_argument("--sync-map-update", action="store_true",
                     help="wait for each scan's local-map update before the step returns (default: async_map_update=1, the "
                          "update overlaps the next step's preprocessing; all of it is inside the timed region either way)")
@@ -76,6 +79,8 @@ def main():
         counts = np.zeros((total, 6), dtype=np.int64)
 
         def step(i):
+            if not args.no_prefetch and i + 1 < total:
+                ctx.prefetch_scan_dev(d_scans[i + 1].data_ptr(), d_labels[i + 1].data_ptr(), n_pts, "")
             ctx.process_scan_dev(d_scans[i].data_ptr(), d_labels[i].data_ptr(), n_pts, None, "", res)
             poses[i] = res.pose[:]
             counts[i] = (res.n_in, res.n_cluster, res.n_ds, res.n_src, res.icp_iterations, res.map_voxels)
@@ -124,7 +129,7 @@ def main():
         "config": {"workload": "synthetic HDL-64-shaped scans (64x1875 = 120000 rays, 20 classes), voxel 1.0 m, max 20 pts/voxel, "
                                "frame-by-frame odometry + semantic graph, one scan stream per GPU (BASELINE.json configs[1])",
                    "shape": args.shape, "points_per_scan": int(n_pts), "preset": "kitti", "graph": not args.no_graph,
-                   "async_map_update": not args.sync_map_update,
+                   "async_map_update": not args.sync_map_update, "prefetch_next_scan": not args.no_prefetch,
                    "mean_n_in": float(tc[:, 0].mean()), "mean_n_cluster": float(tc[:, 1].mean()), "mean_n_ds": float(tc[:, 2].mean()),
                    "mean_n_src": float(tc[:, 3].mean()), "mean_icp_iterations": float(tc[:, 4].mean()),
                    "map_voxels_end": int(tc[-1, 5]),

@@ -190,6 +190,15 @@ int sgs_process_scan_f32(sgs_ctx *ctx, const float *xyzi, const int32_t *label, 
 /* Same, inputs already resident in this context's device memory (DEVICE pointers). */
 int sgs_process_scan_f32_dev(sgs_ctx *ctx, const float *xyzi_dev, const int32_t *label_dev, int n,
                              const double *timestamps_dev, int is_kitti, sgs_scan_result *result);
+/* Optional hint for a caller that already holds the NEXT scan (sequence replay): starts that scan's
+ * front half - crop, the three voxel downsamples, instance clustering + graph, none of which depends on
+ * the scan being registered now - on a second stream and a helper thread, and returns at once.  The
+ * following sgs_process_scan_f32_dev call with the same (xyzi_dev, label_dev, n, is_kitti) picks the
+ * result up; any other call discards it.  The buffers must stay valid and unchanged until then, and the
+ * clouds / boxes of the scan processed before this hint are no longer readable (their storage is reused).
+ * Results are identical with or without the hint.  Ignored when cfg.deskew is set (a scan's deskew needs
+ * the pose of the previous one).  No counterpart in the reference, whose mainProcess is strictly serial. */
+int sgs_prefetch_scan_f32_dev(sgs_ctx *ctx, const float *xyzi_dev, const int32_t *label_dev, int n, int is_kitti);
 /* Clouds of the last processed scan: which = 0 cropped, 1 cluster cloud (0.2 m), 2 frame_downsample,
  * 3 source.  xyz / label optional. */
 int sgs_get_cloud(sgs_ctx *ctx, int which, double *xyz, int32_t *label, int cap, int *n);

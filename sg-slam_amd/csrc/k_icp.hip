@@ -526,7 +526,9 @@ __global__ __launch_bounds__(256) void icp_finish_kernel(DevState *st, const dou
     st->icp_probe += (long long)S[18];
 }
 
-__global__ void icp_init_kernel(DevState *st, Rigid guess, double max_corr, double kernel_th, int max_iter) {
+__global__ void icp_init_kernel(DevState *st, Rigid guess, double max_corr, double kernel_th, int max_iter,
+                                const int32_t *__restrict__ sizes4) {
+    if (sizes4) { st->n_in = sizes4[0]; st->n_c = sizes4[1]; st->n_d = sizes4[2]; st->n_s = sizes4[3]; }
     st->guess = guess;
     st->T_icp = rigid_identity();
     st->T_total = guess;
@@ -563,8 +565,8 @@ __global__ __launch_bounds__(256) void correspondences_kernel(MapView m, CloudVi
 }  // namespace
 
 void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max_corr, double kernel_th, int max_iter,
-                     int) {
-    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, s, st, guess, max_corr, kernel_th, max_iter);
+                     const int32_t *sizes4) {
+    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, s, st, guess, max_corr, kernel_th, max_iter, sizes4);
 }
 
 void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,

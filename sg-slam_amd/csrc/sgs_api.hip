@@ -46,9 +46,9 @@ struct GraphWorker {
     std::thread th;
     std::mutex m;
     std::condition_variable cv;
-    std::function<int()> job;
-    std::atomic<bool> posted{false}, busy{false}, quit{false};
-    int rc = 0;
+    std::function<void()> job;
+    std::atomic<bool> posted{false}, quit{false};
+    std::atomic<int> pending{0};
     void start(int device) {
         th = std::thread([this, device] {
             hipSetDevice(device);
@@ -66,23 +66,24 @@ struct GraphWorker {
                     cv.wait(lk, [this] { return posted.load(std::memory_order_acquire) || quit.load(std::memory_order_acquire); });
                     if (!posted.load(std::memory_order_acquire)) return;  // quit
                 }
-                posted.store(false, std::memory_order_relaxed);
-                std::function<int()> f = std::move(job);
-                rc = f();
-                busy.store(false, std::memory_order_release);
+                std::function<void()> f = std::move(job);
+                posted.store(false, std::memory_order_release);
+                f();
+                pending.fetch_sub(1, std::memory_order_release);
             }
         });
     }
-    void submit(std::function<int()> f) {
+    // one job may run while the next one is posted; completion is tracked by the jobs themselves
+    void submit(std::function<void()> f) {
+        while (posted.load(std::memory_order_acquire)) __builtin_ia32_pause();  // previous post not yet taken
         job = std::move(f);
-        busy.store(true, std::memory_order_relaxed);
+        pending.fetch_add(1, std::memory_order_relaxed);
         posted.store(true, std::memory_order_release);
         std::lock_guard<std::mutex> lk(m);
         cv.notify_all();
     }
-    int wait() {
-        while (busy.load(std::memory_order_acquire)) __builtin_ia32_pause();
-        return rc;
+    void wait_idle() {
+        while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
     }
     void stop() {
         if (!th.joinable()) return;
@@ -97,12 +98,42 @@ struct GraphWorker {
 
 }  // namespace
 
+// Everything one scan's FRONT half (crop, three voxel downsamples, instance clustering + graph)
+// produces and its BACK half (ICP, map update) or the caller consumes.  There are two sets, so the
+// front of scan k+1 (sgs_prefetch_scan_f32_dev) can run on its own stream while scan k registers.
+struct ScanSet {
+    CloudView cropped, cluster, ds, src;
+    int32_t *sizes = nullptr;  // device int32[4]: n_in, n_c, n_d, n_s
+    hipEvent_t ev_ds = nullptr;     // 0.2 m / 0.5 m downsamples done (front stream): the graph stream waits for it
+    hipEvent_t ev_front = nullptr;  // whole front done: the ICP stream waits for it
+    hipEvent_t ev_free = nullptr;   // back half (map update) done reading this set: the next front into it waits
+    bool free_recorded = false;
+    // graph results of the helper thread
+    std::vector<double> boxes;
+    std::vector<float> desc;
+    int n_boxes = 0;
+    int graph_rc = 0;
+    std::string gerr;
+    std::atomic<int> front_enqueued{0};  // ev_front has been recorded (host-side handshake with the helper thread)
+    std::atomic<int> job_done{1};        // the helper thread finished this set's job
+    int front_rc = 0;
+    // which input the set was prefetched for
+    bool prefetched = false;
+    const void *key_xyz = nullptr, *key_label = nullptr;
+    int key_n = 0, key_kitti = 0;
+};
+
 struct sgs_ctx {
     sgs_config cfg;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // ICP, map update and every granular entry point
+    hipStream_t streamF = nullptr;  // front half of a scan
     hipStream_t stream2 = nullptr;  // instance clustering + graph run here, concurrently with the ICP loop
-    hipEvent_t ev_ds = nullptr, ev_g0 = nullptr, ev_g1 = nullptr;
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;
+    ScanSet sets[2];
+    std::mutex front_mu;  // the caller's thread and the helper thread may both enqueue a front: one at a time, whole
+    int cur = 0;
+    ScanSet &S() { return sets[cur]; }
     HostMirror *mirror = nullptr;    // host-pinned, device-mapped: ICP progress, pose / sizes of the scan, map census
     HostMirror *mirror_dev = nullptr;
     bool async_pending = false;      // a map update of sgs_process_scan is still queued (cfg.async_map_update)
@@ -116,7 +147,7 @@ struct sgs_ctx {
     int32_t *in_label = nullptr;
     double *in_ts = nullptr;
     // clouds
-    CloudView tmp, cropped, cluster, ds, src, world, aux;
+    CloudView tmp, world, aux;
     int32_t *flags = nullptr, *blockcnt = nullptr;
     // downsample scratch (two jobs)
     DsEntry *ds_table[2] = {nullptr, nullptr};
@@ -138,8 +169,6 @@ struct sgs_ctx {
     // cluster / graph
     GraphScratch gs;
     GraphWorker gworker;
-    std::string gerr;
-    int job_n_boxes = 0;
 
     // host-side SLAM state (P/SemGraphSLAM.hpp:105-111, F/Threshold.hpp:45-52)
     std::vector<Rigid> poses;
@@ -149,7 +178,6 @@ struct sgs_ctx {
     int map_live_host = 0, map_tomb_host = 0, map_points_host = 0;
     int prev_iters = 6;
     int last_n[5] = {0, 0, 0, 0, 0};
-    std::vector<double> last_boxes;
 
     // profiling
     bool profiling = false;
@@ -380,9 +408,9 @@ int enqueue_icp_iteration(sgs_ctx *c, CloudView src, const int32_t *n_ptr) {
     return SGS_OK;
 }
 
-int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const Rigid &guess, double max_corr, double kernel_th,
-            int *iters_out) {
-    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, 0);
+int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const int32_t *sizes4, const Rigid &guess, double max_corr,
+            double kernel_th, int *iters_out) {
+    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4);
     *iters_out = 0;
     if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
     volatile int32_t *mb = &c->mirror->icp_iter;  // [0] iterations finished, [1] done
@@ -431,62 +459,141 @@ void drain_icp_events(sgs_ctx *c, int iterations_run) {
     c->icp_events_used = 0;
 }
 
+// ---- front half of a scan: crop, the three voxel downsamples, and the instance clustering + graph on
+// the second stream.  Runs on the caller's thread (sgs_process_scan*) or, for a prefetched scan, on the
+// helper thread; touches only the ScanSet it is given and the front-only scratch.
+struct FrontInput {
+    const float *d_f32;
+    const double *d_f64;
+    const int32_t *d_label;
+    const double *d_ts;
+    int n, is_kitti;
+    bool deskew;
+    double delta[6];
+};
+
+int enqueue_front(sgs_ctx *c, ScanSet &S, const FrontInput &in) {
+    // the kernels of one front must be contiguous on the front stream: they share its scratch tables
+    std::lock_guard<std::mutex> front_lock(c->front_mu);
+    hipStream_t f = c->streamF;
+    const sgs_config &cfg = c->cfg;
+    const int n = in.n;
+    // the set may still be read by the map update of the scan before last
+    if (S.free_recorded) SGS_HIP(c, hipStreamWaitEvent(f, S.ev_free, 0));
+    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[0], f);
+    // ---- deskew / KITTI correction / crop (P/SemGraphSLAM.cpp:18-36)
+    PreParams p{};
+    p.crop = 1;
+    p.max_range = cfg.max_range;
+    p.min_range = cfg.min_range;
+    p.mode_kitti = in.is_kitti ? 1 : 0;
+    const double a = (0.205 * M_PI) / 180.0;
+    p.sin_a = sin(a);
+    p.cos_a = cos(a);
+    if (in.deskew) {
+        p.mode_deskew = 1;
+        memcpy(p.delta, in.delta, sizeof(p.delta));
+    }
+    launch_preprocess(f, in.d_f32, in.d_f64, in.d_label, in.d_ts, n, p, c->tmp, c->flags, c->blockcnt, S.cropped, S.sizes + 0);
+    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[1], f);
+    // ---- VoxelizeSemantic (P/SemGraphSLAM.cpp:124-132): 0.2 m and 0.5*voxel grids together, then 1.5*voxel
+    DsJob jobs[2];
+    jobs[0] = make_job(c, 0, S.cropped, S.sizes + 0, cfg.voxel_size_cluster, S.cluster, S.sizes + 1, nullptr);
+    jobs[1] = make_job(c, 1, S.cropped, S.sizes + 0, cfg.voxel_size * 0.5, S.ds, S.sizes + 2, nullptr);
+    launch_downsample(f, jobs, 2, n, c->st);
+    SGS_HIP(c, hipEventRecord(S.ev_ds, f));
+    DsJob j3 = make_job(c, 0, S.ds, S.sizes + 2, cfg.voxel_size * 1.5, S.src, S.sizes + 3, nullptr);
+    launch_downsample(f, &j3, 1, n, c->st);
+    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[2], f);
+    SGS_HIP(c, hipEventRecord(S.ev_front, f));
+    return SGS_OK;
+}
+
+// instance clustering (P/SemGraphSLAM.cpp:41-46) on the 0.2 m cloud + graph: second stream, helper thread
+void graph_job(sgs_ctx *c, ScanSet &S, int n) {
+    const double t_g0 = now_ms();
+    int r = SGS_OK, nb = 0;
+    if (hipStreamWaitEvent(c->stream2, S.ev_ds, 0) != hipSuccess) {
+        S.gerr = "cluster: stream wait failed";
+        r = SGS_EHIP;
+    }
+    if (!r) {
+        if (c->profiling) hipEventRecord(c->ev_g0, c->stream2);
+        r = graph_cluster_enqueue(c->stream2, c->gs, S.cluster, S.sizes + 1, n, c->cfg, true, &S.gerr);
+    }
+    if (!r) r = graph_finish_scan(c->stream2, c->gs, S.cluster, S.sizes + 1, c->cfg, &S.boxes, &nb, &S.gerr);
+    if (!r && c->profiling) hipEventRecord(c->ev_g1, c->stream2);
+    S.n_boxes = nb;
+    S.graph_rc = r;
+    c->stats.stage_ms[5] += now_ms() - t_g0;  // host wall time of cluster enqueue + read-back + graph (helper thread)
+}
+
+// wait until the helper thread is done with a set (front enqueued and graph finished)
+void wait_set_job(ScanSet &S) {
+    while (!S.job_done.load(std::memory_order_acquire)) __builtin_ia32_pause();
+}
+
+// drop a prefetched scan nobody asked for (another entry point was called, or the next scan differs)
+void discard_prefetch(sgs_ctx *c, ScanSet &N) {
+    if (!N.prefetched) return;
+    wait_set_job(N);
+    hipStreamSynchronize(c->streamF);
+    hipStreamSynchronize(c->stream2);
+    N.prefetched = false;
+}
+void discard_prefetch(sgs_ctx *c) {
+    discard_prefetch(c, c->sets[0]);
+    discard_prefetch(c, c->sets[1]);
+}
+
 int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const int32_t *d_label, int n,
                      const double *d_ts, int is_kitti, sgs_scan_result *res) {
     if (n < 0 || n > c->N) return fail(c, SGS_ECAPACITY, "scan of %d points exceeds max_points=%d", n, c->N);
     const double t_call0 = now_ms();
     hipStream_t s = c->stream;
     const sgs_config &cfg = c->cfg;
-    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[0], s);
-    // ---- deskew / KITTI correction / crop (P/SemGraphSLAM.cpp:18-36)
-    PreParams p{};
-    p.crop = 1;
-    p.max_range = cfg.max_range;
-    p.min_range = cfg.min_range;
-    p.mode_kitti = is_kitti ? 1 : 0;
-    const double a = (0.205 * M_PI) / 180.0;
-    p.sin_a = sin(a);
-    p.cos_a = cos(a);
-    if (cfg.deskew && d_ts && c->poses.size() > 2) {
-        const size_t N = c->poses.size();
-        p.mode_deskew = 1;
-        rigid_log(compose(invert(c->poses[N - 2]), c->poses[N - 1]), p.delta);
+    // ---- front half: already under way when this scan was prefetched.  Between a hint for scan k+1 and
+    // the call for scan k both sets can hold a prefetched scan; take the one that matches, else a free one.
+    {
+        const void *kx = d_f32 ? (const void *)d_f32 : (const void *)d_f64;
+        auto matches = [&](const ScanSet &N) {
+            return N.prefetched && N.key_xyz == kx && N.key_label == (const void *)d_label && N.key_n == n && N.key_kitti == is_kitti;
+        };
+        if (matches(c->sets[c->cur ^ 1])) c->cur ^= 1;
+        else if (!matches(c->sets[c->cur])) {
+            if (!c->sets[c->cur ^ 1].prefetched) c->cur ^= 1;             // free (its scan is two calls old)
+            else if (c->sets[c->cur].prefetched) discard_prefetch(c, c->sets[c->cur]);  // both hold hints for other scans
+        }
     }
-    launch_preprocess(s, d_f32, d_f64, d_label, d_ts, n, p, c->tmp, c->flags, c->blockcnt, c->cropped, &c->st->n_in);
-    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[1], s);
-    // ---- VoxelizeSemantic (P/SemGraphSLAM.cpp:124-132): 0.2 m and 0.5*voxel grids together, then 1.5*voxel
-    DsJob jobs[2];
-    jobs[0] = make_job(c, 0, c->cropped, &c->st->n_in, cfg.voxel_size_cluster, c->cluster, &c->st->n_c, nullptr);
-    jobs[1] = make_job(c, 1, c->cropped, &c->st->n_in, cfg.voxel_size * 0.5, c->ds, &c->st->n_d, nullptr);
-    launch_downsample(s, jobs, 2, n, c->st);
-    // ---- instance clustering (P/SemGraphSLAM.cpp:41-46) on the 0.2 m cloud: second stream, overlaps the ICP
-    if (cfg.enable_graph) {
-        SGS_HIP(c, hipEventRecord(c->ev_ds, s));
-        c->gworker.submit([c, n] {  // the helper thread also does the launches: they cost the caller ~30 us otherwise
-            const double t_g0 = now_ms();
-            if (hipStreamWaitEvent(c->stream2, c->ev_ds, 0) != hipSuccess) {
-                c->gerr = "cluster: stream wait failed";
-                return (int)SGS_EHIP;
-            }
-            if (c->profiling) hipEventRecord(c->ev_g0, c->stream2);
-            int r = graph_cluster_enqueue(c->stream2, c->gs, c->cluster, &c->st->n_c, n, c->cfg, true, &c->gerr);
-            if (r) return r;
-            int nb = 0;
-            r = graph_finish_scan(c->stream2, c->gs, c->cluster, &c->st->n_c, c->cfg, &c->last_boxes, &nb, &c->gerr);
-            c->job_n_boxes = nb;
-            if (c->profiling) hipEventRecord(c->ev_g1, c->stream2);
-            c->stats.stage_ms[5] += now_ms() - t_g0;  // host wall time of cluster read-back + graph (helper thread)
-            return r;
-        });
+    ScanSet &S = c->S();
+    if (S.prefetched) {
+        S.prefetched = false;
+        while (!S.front_enqueued.load(std::memory_order_acquire)) __builtin_ia32_pause();
+        if (S.front_rc) return S.front_rc;
+    } else {
+        FrontInput in{d_f32, d_f64, d_label, d_ts, n, is_kitti, false, {0, 0, 0, 0, 0, 0}};
+        if (cfg.deskew && d_ts && c->poses.size() > 2) {
+            const size_t N = c->poses.size();
+            in.deskew = true;
+            rigid_log(compose(invert(c->poses[N - 2]), c->poses[N - 1]), in.delta);
+        }
+        wait_set_job(S);
+        int rf = enqueue_front(c, S, in);
+        if (rf) return rf;
+        if (cfg.enable_graph) {
+            S.job_done.store(0, std::memory_order_relaxed);
+            ScanSet *ps = &S;
+            c->gworker.submit([c, ps, n] {
+                graph_job(c, *ps, n);
+                ps->job_done.store(1, std::memory_order_release);
+            });
+        }
     }
-    struct JobGuard {  // never leave the helper running past this call
-        sgs_ctx *c;
-        bool armed;
-        ~JobGuard() { if (armed) c->gworker.wait(); }
-    } guard{c, cfg.enable_graph != 0};
-    DsJob j3 = make_job(c, 0, c->ds, &c->st->n_d, cfg.voxel_size * 1.5, c->src, &c->st->n_s, nullptr);
-    launch_downsample(s, &j3, 1, n, c->st);
-    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[2], s);
+    struct JobGuard {  // never leave the helper running on this set past this call
+        ScanSet *s;
+        ~JobGuard() { wait_set_job(*s); }
+    } guard{&S};
+    SGS_HIP(c, hipStreamWaitEvent(s, S.ev_front, 0));
     // ---- motion prediction and threshold (P/SemGraphSLAM.cpp:57-63)
     const double sigma = adaptive_threshold(c);
     Rigid prediction = rigid_identity();
@@ -497,7 +604,7 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     // ---- registration (P/SemGraphSLAM.cpp:72-76)
     int iters = 0;
     const double t_icp0 = now_ms();
-    int r = run_icp(c, c->src, &c->st->n_s, guess, 3.0 * sigma, sigma / 3.0, &iters);
+    int r = run_icp(c, S.src, S.sizes + 3, S.sizes, guess, 3.0 * sigma, sigma / 3.0, &iters);
     c->stats.stage_ms[7] += now_ms() - t_icp0;  // host wall time of the ICP loop
     if (r) return r;
     if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[3], s);
@@ -520,8 +627,10 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     }
     r = maybe_rehash(c, n);
     if (r) return r;
-    launch_map_add(s, c->map.v, c->ds, &c->st->n_d, n, &c->st->T_total, c->map_slot_of, c->map_next, c->world, c->st);
+    launch_map_add(s, c->map.v, S.ds, S.sizes + 2, n, &c->st->T_total, c->map_slot_of, c->map_next, c->world, c->st);
     launch_map_sweep(s, c->map.v, &c->st->T_total, nullptr, cfg.max_range, 1, c->map_blockstat, c->st, c->mirror_dev);
+    SGS_HIP(c, hipEventRecord(S.ev_free, s));
+    S.free_recorded = true;
     if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[4], s);
     // ---- collect the clusters, emit boxes in the reference's order, build the graph (P/SemGraphSLAM.cpp:44-51)
     int n_boxes = 0;
@@ -533,13 +642,12 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
         hs = *c->st_host;
     }
     if (cfg.enable_graph) {
-        guard.armed = false;
-        r = c->gworker.wait();
-        if (r) {
-            c->err = c->gerr;
-            return r;
+        wait_set_job(S);
+        if (S.graph_rc) {
+            c->err = S.gerr;
+            return S.graph_rc;
         }
-        n_boxes = c->job_n_boxes;
+        n_boxes = S.n_boxes;
     }
     r = check_err_flags(c, hs.err_flags);
     if (r) return r;
@@ -665,9 +773,13 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(SGS_EHIP);
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return bail(SGS_EHIP);
-    if (hipEventCreateWithFlags(&c->ev_ds, hipEventDisableTiming) != hipSuccess || hipEventCreate(&c->ev_g0) != hipSuccess ||
-        hipEventCreate(&c->ev_g1) != hipSuccess)
-        return bail(SGS_EHIP);
+    if (hipStreamCreateWithFlags(&c->streamF, hipStreamNonBlocking) != hipSuccess) return bail(SGS_EHIP);
+    if (hipEventCreate(&c->ev_g0) != hipSuccess || hipEventCreate(&c->ev_g1) != hipSuccess) return bail(SGS_EHIP);
+    for (ScanSet &S : c->sets)
+        if (hipEventCreateWithFlags(&S.ev_ds, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.ev_front, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.ev_free, hipEventDisableTiming) != hipSuccess)
+            return bail(SGS_EHIP);
     if (hipHostMalloc((void **)&c->mirror, sizeof(HostMirror), hipHostMallocMapped) != hipSuccess) return bail(SGS_ENOMEM);
     if (hipHostGetDevicePointer((void **)&c->mirror_dev, c->mirror, 0) != hipSuccess) return bail(SGS_EHIP);
     memset(c->mirror, 0, sizeof(HostMirror));
@@ -675,9 +787,14 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     if ((r = dev_alloc(c, &c->in_f64, N * 3))) return bail(r);
     if ((r = dev_alloc(c, &c->in_label, N))) return bail(r);
     if ((r = dev_alloc(c, &c->in_ts, N))) return bail(r);
-    CloudView *clouds[] = {&c->tmp, &c->cropped, &c->cluster, &c->ds, &c->src, &c->world, &c->aux};
+    CloudView *clouds[] = {&c->tmp, &c->world, &c->aux, &c->sets[0].cropped, &c->sets[0].cluster, &c->sets[0].ds, &c->sets[0].src,
+                           &c->sets[1].cropped, &c->sets[1].cluster, &c->sets[1].ds, &c->sets[1].src};
     for (CloudView *v : clouds)
         if ((r = alloc_cloud(c, v, N))) return bail(r);
+    for (ScanSet &S : c->sets) {
+        if ((r = dev_alloc(c, &S.sizes, 4))) return bail(r);
+        if (hipMemsetAsync(S.sizes, 0, 4 * sizeof(int32_t), c->stream) != hipSuccess) return bail(SGS_EHIP);
+    }
     if ((r = dev_alloc(c, &c->flags, N))) return bail(r);
     if ((r = dev_alloc(c, &c->blockcnt, N / 256 + 2))) return bail(r);
     size_t Bmax = 1;
@@ -717,10 +834,17 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
 void sgs_destroy(sgs_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    c->gworker.wait_idle();
     c->gworker.stop();
+    if (c->streamF) hipStreamSynchronize(c->streamF);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) hipStreamSynchronize(c->stream2);
-    if (c->ev_ds) hipEventDestroy(c->ev_ds);
+    for (ScanSet &S : c->sets) {
+        if (S.ev_ds) hipEventDestroy(S.ev_ds);
+        if (S.ev_front) hipEventDestroy(S.ev_front);
+        if (S.ev_free) hipEventDestroy(S.ev_free);
+    }
+    if (c->streamF) hipStreamDestroy(c->streamF);
     if (c->ev_g0) hipEventDestroy(c->ev_g0);
     if (c->ev_g1) hipEventDestroy(c->ev_g1);
     if (c->mirror) hipHostFree(c->mirror);
@@ -766,6 +890,7 @@ int sgs_set_profiling(sgs_ctx *c, int enable) {
 // every entry point except sgs_process_scan* first waits for a map update still queued by it
 #define ENTER(c)                          \
     ENTER_NOSETTLE(c);                    \
+    discard_prefetch(c);                  \
     if ((c)->async_pending) {             \
         const int rs_ = sync_state(c);    \
         if (rs_) return rs_;              \
@@ -836,8 +961,8 @@ int sgs_voxel_downsample(sgs_ctx *c, const double *xyz, const int32_t *label, in
     CHECK_N(c, n);
     if ((n && (!xyz || !label)) || !out_n || !(voxel_size > 0)) return fail(c, SGS_EINVAL, "bad argument");
     int r;
-    if ((r = upload_xyz(c, xyz, n, c->cropped, label))) return r;  // aux_n[0] = n
-    DsJob j = make_job(c, 0, c->cropped, &c->aux_n[0], voxel_size, c->aux, &c->aux_n[1], c->ds_index);
+    if ((r = upload_xyz(c, xyz, n, c->world, label))) return r;  // aux_n[0] = n
+    DsJob j = make_job(c, 0, c->world, &c->aux_n[0], voxel_size, c->aux, &c->aux_n[1], c->ds_index);
     launch_downsample(c->stream, &j, 1, n, c->st);
     int m = 0;
     if (n == 0) { *out_n = 0; return SGS_OK; }
@@ -872,7 +997,7 @@ static int map_add_common(sgs_ctx *c, const double *xyzl, int n, const double *p
     if ((r = upload_xyzl(c, xyzl, n, c->aux))) return r;  // aux_n[0] = n
     const Rigid *T_dev = nullptr;
     if (pose7) {
-        launch_icp_init(c->stream, c->st, rigid_from_pose7(pose7), 0, 0, 0, 0);  // parks the pose in st->T_total
+        launch_icp_init(c->stream, c->st, rigid_from_pose7(pose7), 0, 0, 0, nullptr);  // parks the pose in st->T_total
         T_dev = &c->st->T_total;
     }
     launch_map_add(c->stream, c->map.v, c->aux, &c->aux_n[0], n, T_dev, c->map_slot_of, c->map_next, c->world, c->st);
@@ -1006,7 +1131,7 @@ int sgs_build_linear_system(sgs_ctx *c, const double *xyzl_world, int n, double 
     if ((n && !xyzl_world) || !out27) return fail(c, SGS_EINVAL, "null argument");
     int r;
     if ((r = upload_xyzl(c, xyzl_world, n, c->aux))) return r;  // aux_n[0] = n
-    launch_icp_init(c->stream, c->st, rigid_identity(), max_distance, kernel, 1, 1);
+    launch_icp_init(c->stream, c->st, rigid_identity(), max_distance, kernel, 1, nullptr);
     launch_icp_iteration(c->stream, c->map.v, c->aux, c->N, &c->aux_n[0], c->st, c->partials, false, nullptr);
     launch_linear_system_finish(c->stream, c->st, c->partials, c->out28);
     double h[28];
@@ -1026,7 +1151,7 @@ int sgs_register_frame(sgs_ctx *c, const double *xyzl, int n, const double *gues
     if ((r = upload_xyzl(c, xyzl, n, c->aux))) return r;  // aux_n[0] = n
     int iters = 0;
     const Rigid guess = rigid_from_pose7(guess7);
-    if ((r = run_icp(c, c->aux, &c->aux_n[0], guess, max_corr, kernel, &iters))) return r;
+    if ((r = run_icp(c, c->aux, &c->aux_n[0], nullptr, guess, max_corr, kernel, &iters))) return r;
     if ((r = sync_state(c))) return r;
     if (c->profiling) drain_icp_events(c, iters);
     rigid_to_pose7(c->st_host->T_total, out_pose7);
@@ -1069,9 +1194,9 @@ int sgs_process_scan(sgs_ctx *c, const double *xyz, const int32_t *label, int n,
     ENTER_NOSETTLE(c);
     CHECK_N(c, n);
     if (n && (!xyz || !label)) return fail(c, SGS_EINVAL, "null argument");
-    SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    if (ts) SGS_HIP(c, hipMemcpyAsync(c->in_ts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
+    SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
+    if (ts) SGS_HIP(c, hipMemcpyAsync(c->in_ts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
     return process_scan_dev(c, nullptr, c->in_f64, c->in_label, n, ts ? c->in_ts : nullptr, is_kitti, res);
 }
 int sgs_process_scan_f32(sgs_ctx *c, const float *xyzi, const int32_t *label, int n, const double *ts, int is_kitti,
@@ -1079,9 +1204,9 @@ int sgs_process_scan_f32(sgs_ctx *c, const float *xyzi, const int32_t *label, in
     ENTER_NOSETTLE(c);
     CHECK_N(c, n);
     if (n && (!xyzi || !label)) return fail(c, SGS_EINVAL, "null argument");
-    SGS_HIP(c, hipMemcpyAsync(c->in_f32, xyzi, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    if (ts) SGS_HIP(c, hipMemcpyAsync(c->in_ts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    SGS_HIP(c, hipMemcpyAsync(c->in_f32, xyzi, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
+    SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
+    if (ts) SGS_HIP(c, hipMemcpyAsync(c->in_ts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
     return process_scan_dev(c, c->in_f32, nullptr, c->in_label, n, ts ? c->in_ts : nullptr, is_kitti, res);
 }
 int sgs_process_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *label_dev, int n, const double *ts_dev,
@@ -1091,10 +1216,36 @@ int sgs_process_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *l
     if (n && (!xyzi_dev || !label_dev)) return fail(c, SGS_EINVAL, "null argument");
     return process_scan_dev(c, xyzi_dev, nullptr, label_dev, n, ts_dev, is_kitti, res);
 }
+int sgs_prefetch_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *label_dev, int n, int is_kitti) {
+    ENTER_NOSETTLE(c);
+    CHECK_N(c, n);
+    if (n && (!xyzi_dev || !label_dev)) return fail(c, SGS_EINVAL, "null argument");
+    if (c->cfg.deskew) return SGS_OK;  // the deskew of a scan needs the pose of the one before it: nothing to run ahead
+    // the set that holds no pending hint: normally the one whose scan the caller has just finished with
+    ScanSet &N = c->sets[c->cur ^ 1].prefetched ? c->sets[c->cur] : c->sets[c->cur ^ 1];
+    if (N.prefetched) return SGS_OK;  // two hints already pending: ignore this one
+    wait_set_job(N);
+    N.prefetched = true;
+    N.key_xyz = xyzi_dev; N.key_label = label_dev; N.key_n = n; N.key_kitti = is_kitti;
+    N.front_enqueued.store(0, std::memory_order_relaxed);
+    N.job_done.store(0, std::memory_order_relaxed);
+    N.front_rc = SGS_OK;
+    ScanSet *ps = &N;
+    const bool graph = c->cfg.enable_graph != 0;
+    c->gworker.submit([c, ps, xyzi_dev, label_dev, n, is_kitti, graph] {
+        const FrontInput in{xyzi_dev, nullptr, label_dev, nullptr, n, is_kitti, false, {0, 0, 0, 0, 0, 0}};
+        ps->front_rc = enqueue_front(c, *ps, in);
+        ps->front_enqueued.store(1, std::memory_order_release);
+        if (graph && !ps->front_rc) graph_job(c, *ps, n);
+        ps->job_done.store(1, std::memory_order_release);
+    });
+    return SGS_OK;
+}
 int sgs_get_cloud(sgs_ctx *c, int which, double *xyz, int32_t *label, int cap, int *n) {
     ENTER(c);
     if (which < 0 || which > 3 || !n) return fail(c, SGS_EINVAL, "bad argument");
-    const CloudView v = which == 0 ? c->cropped : which == 1 ? c->cluster : which == 2 ? c->ds : c->src;
+    const ScanSet &S = c->S();
+    const CloudView v = which == 0 ? S.cropped : which == 1 ? S.cluster : which == 2 ? S.ds : S.src;
     const int m = c->last_n[which + 1];
     *n = m;
     int r = download_cloud(c, v, std::min(m, cap), xyz, label);
@@ -1104,9 +1255,10 @@ int sgs_get_cloud(sgs_ctx *c, int which, double *xyz, int32_t *label, int cap, i
 int sgs_get_boxes(sgs_ctx *c, double *boxes, int cap, int *n) {
     ENTER(c);
     if (!n) return SGS_EINVAL;
-    const int m = (int)(c->last_boxes.size() / 8);
+    const std::vector<double> &last_boxes = c->S().boxes;
+    const int m = (int)(last_boxes.size() / 8);
     *n = m;
-    if (boxes) memcpy(boxes, c->last_boxes.data(), sizeof(double) * 8 * (size_t)std::min(m, cap));
+    if (boxes) memcpy(boxes, last_boxes.data(), sizeof(double) * 8 * (size_t)std::min(m, cap));
     return m > cap ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", cap, m) : SGS_OK;
 }
 int sgs_get_poses(sgs_ctx *c, double *poses7, int cap, int *n) {

@@ -122,8 +122,9 @@ void launch_map_rehash(hipStream_t s, MapView from, MapView to, DevState *st);
 void launch_map_clear(hipStream_t s, MapView m, DevState *st);
 
 // ---- k_icp.hip ----
+// sizes4 (nullable): device int32[4] {n_in, n_c, n_d, n_s} of the scan, copied into DevState
 void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max_corr, double kernel_th,
-                     int max_iter, int prior_world /*1: source already in world frame*/);
+                     int max_iter, const int32_t *sizes4);
 // one Gauss-Newton iteration in ONE kernel: fused correspondence search + linear-system reduction;
 // with solve=true the last block to publish its partials folds them and runs the 6x6 solve + pose
 // update + convergence test (no second dispatch).  solve=false leaves the partials for

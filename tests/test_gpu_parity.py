@@ -446,6 +446,48 @@ def test_pipeline_async_map_update_matches_sync():
     b.close()
 
 
+def test_pipeline_prefetch_matches_serial():
+    """sgs_prefetch_scan_f32_dev runs the next scan's front half early on another stream/thread; every
+    result must be bit-identical to the serial call sequence, also when a hint is wrong or unused."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself is linked against
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+
+    def to_dev(arr):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), arr.nbytes) == 0
+        assert hip.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        return p
+
+    frames = 24
+    scans = [_scan(k, "small") for k in range(frames)]
+    a, b = make_ctx(async_map_update=1), make_ctx()
+    d_xyzi = [to_dev(np.ascontiguousarray(s[0], dtype=np.float32)) for s in scans]
+    d_lab = [to_dev(np.ascontiguousarray(s[2], dtype=np.int32)) for s in scans]
+    for k in range(frames):
+        n = len(scans[k][2])
+        if k + 1 < frames and k % 7 != 3:        # sometimes no hint at all
+            nxt = k + 1 if k % 5 != 2 else k     # sometimes a wrong hint (not the scan that follows)
+            a.prefetch_scan_dev(d_xyzi[nxt], d_lab[nxt], len(scans[nxt][2]), "")
+        ra = a.process_scan_dev(d_xyzi[k], d_lab[k], n)
+        rb = b.process_scan_dev(d_xyzi[k], d_lab[k], n)
+        assert list(ra.pose) == list(rb.pose) and ra.icp_iterations == rb.icp_iterations, k
+        assert (ra.n_in, ra.n_cluster, ra.n_ds, ra.n_src, ra.n_boxes) == (rb.n_in, rb.n_cluster, rb.n_ds, rb.n_src, rb.n_boxes)
+        if k % 4 == 1:   # accessors in between discard a pending hint and must still see scan k
+            assert np.array_equal(a.boxes(), b.boxes())
+            for which in (0, 1, 2, 3):
+                xa, la = a.cloud(which)
+                xb, lb = b.cloud(which)
+                assert np.array_equal(xa, xb) and np.array_equal(la, lb)
+    assert a.map_size() == b.map_size() and np.array_equal(a.poses(), b.poses())
+    a.close()
+    b.close()
+    for p in d_xyzi + d_lab:
+        hip.hipFree(p)
+
+
 def test_error_behaviour():
     ctx = make_ctx(max_points=1024)
     big = np.zeros((2000, 3))
