@@ -77,7 +77,7 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
                 ++probes;
                 if (raw.x == pk) {
                     slot = (int)s;
-                    cnt = (uint32_t)(raw.y & 0xFFFFFFFFull);
+                    cnt = (uint32_t)(raw.y & 0xFFull);  // stored points (the upper bits count a batch in flight, k_map.hip)
                     break;
                 }
                 if (raw.x == kEmptyKey) break;

@@ -5,11 +5,13 @@
 //
 // AddPoints semantics to preserve (F/VoxelHashMap.cpp:164-176): points are inserted sequentially in
 // input order and a voxel keeps at most `cap` points first-come.  Parallel version:
-//   add kernel     every point finds-or-claims its slot (atomicCAS on the key) and pushes itself on
-//                  the slot's pending list (atomicExch on head)
-//   append kernel  the point that ended up as list head owns the slot: it walks the list, picks the
-//                  (cap - cnt) smallest input indices in ascending order and appends exactly those,
-//                  which is what the sequential loop would have stored.
+//   add kernel     every point finds-or-claims its slot (atomicCAS on the key), pushes itself on the
+//                  slot's pending list (atomicExch on head) and counts itself in the upper 24 bits
+//                  of the slot's count word
+//   append kernel  every point walks its voxel's pending list ONCE to find its rank among the
+//                  pending points by input index; rank r goes to position cnt + r if that is below
+//                  cap - exactly the points the sequential loop would have stored, in its order
+//   sweep kernel   (always follows) folds the pending count into the count and clears the list head.
 // Prune (F/VoxelHashMap.cpp:178-186): a sweep over the slot headers that tombstones voxels whose
 // oldest point is farther than max_distance from the origin (pure predicate; the reference's
 // erase-while-iterating skip quirk is layout dependent and not reproduced).
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(kBlock) void map_add_kernel(MapView m, CloudView in
     }
     slot_of[i] = found;
     next[i] = atomicExch(&m.slots[found].head, i);
+    atomicAdd(&m.slots[found].cnt, 1u << 8);  // pending points of this batch (the stored count is <= 255)
 }
 
 __global__ __launch_bounds__(kBlock) void map_append_kernel(MapView m, CloudView in, const int32_t *__restrict__ n_ptr,
@@ -83,29 +86,23 @@ __global__ __launch_bounds__(kBlock) void map_append_kernel(MapView m, CloudView
     if (i >= n) return;
     const int s = slot_of[i];
     if (s < 0) return;
-    if (m.slots[s].head != i) return;  // only the list head processes the voxel
-    const uint32_t cnt0 = m.slots[s].cnt;
-    const int room = m.cap - (int)cnt0;
-    const K3 k = unpack_key(m.slots[s].key);
+    // header: stable during this kernel (the sweep that follows finalises count and head)
+    const ulonglong2 raw = reinterpret_cast<const ulonglong2 *>(m.slots)[s];
+    const uint32_t cntword = (uint32_t)(raw.y & 0xFFFFFFFFull);
+    const int cnt0 = (int)(cntword & 0xFFu);
+    if (cnt0 >= m.cap) return;
+    const int head = (int)(uint32_t)(raw.y >> 32);
+    int rank = 0;
+    for (int j = head; j >= 0; j = next[j]) rank += (j < i) ? 1 : 0;
+    const int pos = cnt0 + rank;
+    if (pos >= m.cap) return;
+    const K3 k = unpack_key(raw.x);
     const double ox = (double)k.x * m.voxel, oy = (double)k.y * m.voxel, oz = (double)k.z * m.voxel;
-    int last = -1, written = 0;
-    for (int r = 0; r < room; ++r) {
-        int best = INT_MAX;
-        for (int j = i; j >= 0; j = next[j])
-            if (j > last && j < best) best = j;
-        if (best == INT_MAX) break;
-        const double wx = world.x[best], wy = world.y[best], wz = world.z[best];
-        const uint32_t slotpos = cnt0 + (uint32_t)written;
-        m.pts[(size_t)s * m.cap + slotpos] =
-            make_float4((float)(wx - ox), (float)(wy - oy), (float)(wz - oz), __int_as_float(in.l[best]));
-        if (slotpos == 0) {
-            m.first[3 * (size_t)s] = wx; m.first[3 * (size_t)s + 1] = wy; m.first[3 * (size_t)s + 2] = wz;
-        }
-        last = best;
-        ++written;
+    const double wx = world.x[i], wy = world.y[i], wz = world.z[i];
+    m.pts[(size_t)s * m.cap + pos] = make_float4((float)(wx - ox), (float)(wy - oy), (float)(wz - oz), __int_as_float(in.l[i]));
+    if (pos == 0) {
+        m.first[3 * (size_t)s] = wx; m.first[3 * (size_t)s + 1] = wy; m.first[3 * (size_t)s + 2] = wz;
     }
-    m.slots[s].cnt = cnt0 + (uint32_t)written;
-    m.slots[s].head = -1;
     (void)st;
 }
 
@@ -118,8 +115,14 @@ __global__ __launch_bounds__(kBlock) void map_prune_kernel(MapView m, const Rigi
     if (s <= m.mask) {
         const ulonglong2 raw = reinterpret_cast<const ulonglong2 *>(m.slots)[s];
         const unsigned long long key = raw.x;
-        const int cnt = (int)(uint32_t)(raw.y & 0xFFFFFFFFull);
+        const uint32_t cntword = (uint32_t)(raw.y & 0xFFFFFFFFull);
+        int cnt = (int)(cntword & 0xFFu);
         const bool valid = key != kTombKey && key != kEmptyKey;
+        const int pending = (int)(cntword >> 8);
+        if (pending) {  // a batch of map_add: stored = min(cap, stored + pending), list consumed
+            cnt = min(m.cap, cnt + pending);
+            if (valid) reinterpret_cast<ulonglong2 *>(m.slots)[s] = make_ulonglong2(key, 0xFFFFFFFF00000000ull | (unsigned long long)(uint32_t)cnt);
+        }
         bool kill = false;
         if (valid && do_prune) {
             const D3 o = T_dev ? T_dev->t : origin_host;
