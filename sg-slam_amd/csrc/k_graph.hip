@@ -771,9 +771,12 @@ int graph_scratch_alloc(GraphScratch &g, int N) {
               galloc(&g.parent, n + 16) && galloc(&g.stat, n + 16) && galloc(&g.pt_cluster, n) &&
               galloc(&g.boxes_dev, (size_t)kMaxClusters * 8) && galloc(&g.edge_dev, (size_t)kMaxNodes * kMaxNodes) &&
               galloc(&g.hist_dev, (size_t)kMaxNodes * kMaxHistCols) && galloc(&g.n_boxes_dev, 4);
-    if (ok) ok = hipHostMalloc((void **)&g.hostblk, kHbBytes, hipHostMallocMapped) == hipSuccess &&
-                 hipHostGetDevicePointer((void **)&g.hostblk_dev, g.hostblk, 0) == hipSuccess;
-    if (ok) memset(g.hostblk, 0, kHbRecs);
+    for (GraphSlot &q : g.slot) {
+        if (ok) ok = hipHostMalloc((void **)&q.hostblk, kHbBytes, hipHostMallocMapped) == hipSuccess &&
+                     hipHostGetDevicePointer((void **)&q.hostblk_dev, q.hostblk, 0) == hipSuccess &&
+                     hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming) == hipSuccess;
+        if (ok) memset(q.hostblk, 0, kHbRecs);
+    }
     return ok ? SGS_OK : SGS_ENOMEM;
 }
 
@@ -782,7 +785,10 @@ void graph_scratch_free(GraphScratch &g) {
                   g.range_ext, g.cslot, g.plabel, g.table, g.parent, g.stat, g.pt_cluster, g.boxes_dev, g.edge_dev, g.hist_dev, g.n_boxes_dev};
     for (void *p : ps)
         if (p) hipFree(p);
-    if (g.hostblk) hipHostFree(g.hostblk);
+    for (GraphSlot &q : g.slot) {
+        if (q.hostblk) hipHostFree(q.hostblk);
+        if (q.ev_done) hipEventDestroy(q.ev_done);
+    }
     g = GraphScratch();
 }
 
@@ -798,10 +804,11 @@ int graph_params_check(double edge_dis_th, int subinterval, int dim, int *sub_in
 // Every cluster kernel and, with with_graph, the edge / histogram kernel on the boxes in device order:
 // one dependent chain on the stream, results written by the kernels into host-mapped memory, no copy
 // and no host sync in between.
-int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper,
+int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, int slot, CloudView in, const int32_t *n_ptr, int n_upper,
                           const sgs_config &cfg, bool with_graph, std::string *err) {
-    g.enqueued_upper = n_upper;
-    g.enqueued_graph = false;
+    GraphSlot &q = g.slot[slot];
+    q.enqueued_upper = n_upper;
+    q.enqueued_graph = false;
     if (n_upper <= 0) return SGS_OK;
     if (!(cfg.deltaA > 0) || !(cfg.deltaR > 0) || !(cfg.deltaP > 0)) return gfail(err, SGS_EINVAL, "cluster deltas must be positive");
     int sub_interval_value = 0;
@@ -823,7 +830,7 @@ int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const in
                        g.fg_all, g.bg_all, g.pol_azi, g.apr_range, g.range_ext);
     hipLaunchKernelGGL(cluster_class_kernel, dim3(kNumFgClasses), dim3(kCluThreads), 0, s, in, g.params, g.fg_order, g.pol_azi,
                        g.apr_range, g.range_ext, K, g.cslot, g.plabel, g.table, g.parent, g.stat, g.pt_cluster);
-    char *hb = g.hostblk_dev;
+    char *hb = q.hostblk_dev;
     hipLaunchKernelGGL(cluster_boxes_kernel, dim3(1), dim3(kBlock), 0, s, g.params, g.counts, g.stat,
                        reinterpret_cast<GraphHostHeader *>(hb), reinterpret_cast<ClusterRec *>(hb + kHbRecs), kMaxClusters,
                        reinterpret_cast<double *>(hb + kHbBoxes), g.boxes_dev, kMaxClusters, kMaxNodes, g.n_boxes_dev);
@@ -831,27 +838,31 @@ int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const in
         hipLaunchKernelGGL(graph_edges_kernel, dim3(kMaxNodes), dim3(128), sizeof(int) * 3 * (size_t)cfg.subinterval, s,
                            g.boxes_dev, g.n_boxes_dev, 0, cfg.edge_dis_th, sub_interval_value, cfg.subinterval,
                            reinterpret_cast<double *>(hb + kHbEdge), reinterpret_cast<int32_t *>(hb + kHbHist));
-        g.enqueued_graph = true;
+        q.enqueued_graph = true;
     }
-    if (hipGetLastError() != hipSuccess) return gfail(err, SGS_EHIP, "cluster: launch failed");
+    if (hipGetLastError() != hipSuccess || hipEventRecord(q.ev_done, s) != hipSuccess)
+        return gfail(err, SGS_EHIP, "cluster: launch failed");
     return SGS_OK;
 }
 
 // Waits for the cluster kernels and emits the boxes in the reference's order; box_perm (optional)
 // receives, per emitted box, its index in the device-order list the edge kernel worked on.
-int graph_cluster_finish(hipStream_t s, GraphScratch &g, const int32_t *n_ptr, std::vector<double> *boxes, int *n_boxes,
-                         int32_t *point_cluster_host, int *n_fg, int *n_bg, std::vector<int> *box_perm, std::string *err) {
+int graph_cluster_finish(hipStream_t s, GraphScratch &g, int slot, const int32_t *n_ptr, std::vector<double> *boxes,
+                         int *n_boxes, int32_t *point_cluster_host, int *n_fg, int *n_bg, std::vector<int> *box_perm,
+                         std::string *err) {
+    GraphSlot &q = g.slot[slot];
     if (boxes) boxes->clear();
     if (box_perm) box_perm->clear();
     if (n_boxes) *n_boxes = 0;
     if (n_fg) *n_fg = 0;
     if (n_bg) *n_bg = 0;
-    if (g.enqueued_upper <= 0) return SGS_OK;
-    if (hipStreamSynchronize(s) != hipSuccess) return gfail(err, SGS_EHIP, "cluster: device error");
-    const GraphHostHeader &hdr = *reinterpret_cast<const GraphHostHeader *>(g.hostblk);
-    const ClusterRec *recs = reinterpret_cast<const ClusterRec *>(g.hostblk + kHbRecs);
-    const double *hb_boxes = reinterpret_cast<const double *>(g.hostblk + kHbBoxes);
-    memcpy(g.params_host, hdr.params, sizeof(ClassParams) * kNumFgClasses);
+    if (q.enqueued_upper <= 0) return SGS_OK;
+    // only this slot's kernels: the next scan's may already be queued behind them on the stream
+    if (hipEventSynchronize(q.ev_done) != hipSuccess) return gfail(err, SGS_EHIP, "cluster: device error");
+    const GraphHostHeader &hdr = *reinterpret_cast<const GraphHostHeader *>(q.hostblk);
+    const ClusterRec *recs = reinterpret_cast<const ClusterRec *>(q.hostblk + kHbRecs);
+    const double *hb_boxes = reinterpret_cast<const double *>(q.hostblk + kHbBoxes);
+    memcpy(q.params_host, hdr.params, sizeof(ClassParams) * kNumFgClasses);
     if (n_fg) *n_fg = hdr.counts[5];
     if (n_bg) *n_bg = hdr.counts[6];
     if (hdr.n_clusters > kMaxClusters) return gfail(err, SGS_ECAPACITY, "more instance clusters than the result block holds");
@@ -892,9 +903,9 @@ int graph_cluster_finish(hipStream_t s, GraphScratch &g, const int32_t *n_ptr, s
 int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper, const sgs_config &cfg,
                   std::vector<double> *boxes, int *n_boxes, int32_t *point_cluster_host, int *n_fg, int *n_bg,
                   std::string *err) {
-    int r = graph_cluster_enqueue(s, g, in, n_ptr, n_upper, cfg, false, err);
+    int r = graph_cluster_enqueue(s, g, 0, in, n_ptr, n_upper, cfg, false, err);
     if (r) return r;
-    return graph_cluster_finish(s, g, n_ptr, boxes, n_boxes, point_cluster_host, n_fg, n_bg, nullptr, err);
+    return graph_cluster_finish(s, g, 0, n_ptr, boxes, n_boxes, point_cluster_host, n_fg, n_bg, nullptr, err);
 }
 
 namespace {
@@ -1019,21 +1030,22 @@ int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, dou
 
 // pipeline tail: boxes in the reference's order, then the edge matrix / histogram rows the device
 // computed in ITS box order are permuted into that order and the spectral half runs on the host
-int graph_finish_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, const sgs_config &cfg,
+int graph_finish_scan(hipStream_t s, GraphScratch &g, int slot, CloudView in, const int32_t *n_ptr, const sgs_config &cfg,
                       std::vector<double> *boxes, int *n_boxes, std::string *err) {
     (void)in;
-    std::vector<int> &perm = g.box_perm;
-    int r = graph_cluster_finish(s, g, n_ptr, boxes, n_boxes, nullptr, nullptr, nullptr, &perm, err);
+    GraphSlot &q = g.slot[slot];
+    std::vector<int> &perm = q.box_perm;
+    int r = graph_cluster_finish(s, g, slot, n_ptr, boxes, n_boxes, nullptr, nullptr, nullptr, &perm, err);
     if (r) return r;
     const int nb = *n_boxes;
-    if (nb == 0 || !g.enqueued_graph) return SGS_OK;
+    if (nb == 0 || !q.enqueued_graph) return SGS_OK;
     if (nb > kMaxNodes) return gfail(err, SGS_ECAPACITY, "too many graph nodes");
-    const GraphHostHeader &hdr = *reinterpret_cast<const GraphHostHeader *>(g.hostblk);
+    const GraphHostHeader &hdr = *reinterpret_cast<const GraphHostHeader *>(q.hostblk);
     const int nd = hdr.n_boxes;  // device-order box count (== nb: every kept box is emitted exactly once)
     if (nd != nb) return gfail(err, SGS_EHIP, "graph: box count mismatch");
     const int cols = 3 * cfg.subinterval;
-    const double *Ed = reinterpret_cast<const double *>(g.hostblk + kHbEdge);
-    const int32_t *Hd = reinterpret_cast<const int32_t *>(g.hostblk + kHbHist);
+    const double *Ed = reinterpret_cast<const double *>(q.hostblk + kHbEdge);
+    const int32_t *Hd = reinterpret_cast<const int32_t *>(q.hostblk + kHbHist);
     std::vector<double> E((size_t)nb * nb);
     std::vector<int32_t> H((size_t)nb * cols);
     for (int i = 0; i < nb; ++i) {
@@ -1041,10 +1053,10 @@ int graph_finish_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_
         for (int j = 0; j < nb; ++j) E[(size_t)i * nb + j] = Ed[pi * nd + (size_t)perm[(size_t)j]];
         memcpy(&H[(size_t)i * cols], Hd + pi * cols, sizeof(int32_t) * (size_t)cols);
     }
-    g.last_desc.assign((size_t)nb * (3 * cfg.subinterval + cfg.graph_node_dimension), 0.f);
+    q.last_desc.assign((size_t)nb * (3 * cfg.subinterval + cfg.graph_node_dimension), 0.f);
     int ne = 0, nt = 0;
     return graph_host_part(boxes->data(), nb, cfg.edge_dis_th, cfg.subinterval, cfg.graph_node_dimension, cfg.subgraph_edge_th,
-                           E, H, g.last_desc.data(), nullptr, nullptr, nullptr, nullptr, nullptr, 0, &ne, nullptr, nullptr, 0,
+                           E, H, q.last_desc.data(), nullptr, nullptr, nullptr, nullptr, nullptr, 0, &ne, nullptr, nullptr, 0,
                            &nt, nullptr, err);
 }
 

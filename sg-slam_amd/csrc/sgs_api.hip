@@ -168,7 +168,8 @@ struct sgs_ctx {
     DevState *st_host = nullptr;  // pinned
     // cluster / graph
     GraphScratch gs;
-    GraphWorker gworker;
+    GraphWorker gworker;  // launches: front half of prefetched scans, cluster / graph kernels
+    GraphWorker fworker;  // waits for the cluster / graph kernels and finishes the graph on the host
 
     // host-side SLAM state (P/SemGraphSLAM.hpp:105-111, F/Threshold.hpp:45-52)
     std::vector<Rigid> poses;
@@ -509,23 +510,32 @@ int enqueue_front(sgs_ctx *c, ScanSet &S, const FrontInput &in) {
     return SGS_OK;
 }
 
-// instance clustering (P/SemGraphSLAM.cpp:41-46) on the 0.2 m cloud + graph: second stream, helper thread
-void graph_job(sgs_ctx *c, ScanSet &S, int n) {
-    const double t_g0 = now_ms();
-    int r = SGS_OK, nb = 0;
+// instance clustering (P/SemGraphSLAM.cpp:41-46) on the 0.2 m cloud + graph, second stream.  Two helper
+// threads: the first only LAUNCHES (front half of a prefetched scan, then these kernels), the second
+// waits for the kernels and finishes the graph on the host (box order, eigen-decomposition), so the
+// launches for the next scan never wait behind a device synchronisation.
+void graph_enqueue_job(sgs_ctx *c, ScanSet &S, int slot, int n) {
+    int r = SGS_OK;
     if (hipStreamWaitEvent(c->stream2, S.ev_ds, 0) != hipSuccess) {
         S.gerr = "cluster: stream wait failed";
         r = SGS_EHIP;
     }
     if (!r) {
         if (c->profiling) hipEventRecord(c->ev_g0, c->stream2);
-        r = graph_cluster_enqueue(c->stream2, c->gs, S.cluster, S.sizes + 1, n, c->cfg, true, &S.gerr);
+        r = graph_cluster_enqueue(c->stream2, c->gs, slot, S.cluster, S.sizes + 1, n, c->cfg, true, &S.gerr);
+        if (!r && c->profiling) hipEventRecord(c->ev_g1, c->stream2);
     }
-    if (!r) r = graph_finish_scan(c->stream2, c->gs, S.cluster, S.sizes + 1, c->cfg, &S.boxes, &nb, &S.gerr);
-    if (!r && c->profiling) hipEventRecord(c->ev_g1, c->stream2);
-    S.n_boxes = nb;
     S.graph_rc = r;
-    c->stats.stage_ms[5] += now_ms() - t_g0;  // host wall time of cluster enqueue + read-back + graph (helper thread)
+    ScanSet *ps = &S;
+    c->fworker.submit([c, ps, slot] {
+        const double t_g0 = now_ms();
+        int nb = 0;
+        if (!ps->graph_rc)
+            ps->graph_rc = graph_finish_scan(c->stream2, c->gs, slot, ps->cluster, ps->sizes + 1, c->cfg, &ps->boxes, &nb, &ps->gerr);
+        ps->n_boxes = nb;
+        c->stats.stage_ms[5] += now_ms() - t_g0;  // host wall time of cluster read-back + graph (second helper thread)
+        ps->job_done.store(1, std::memory_order_release);
+    });
 }
 
 // wait until the helper thread is done with a set (front enqueued and graph finished)
@@ -583,10 +593,8 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
         if (cfg.enable_graph) {
             S.job_done.store(0, std::memory_order_relaxed);
             ScanSet *ps = &S;
-            c->gworker.submit([c, ps, n] {
-                graph_job(c, *ps, n);
-                ps->job_done.store(1, std::memory_order_release);
-            });
+            const int slot = c->cur;
+            c->gworker.submit([c, ps, slot, n] { graph_enqueue_job(c, *ps, slot, n); });
         }
     }
     struct JobGuard {  // never leave the helper running on this set past this call
@@ -821,6 +829,7 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     if ((r = alloc_map(c, &c->map, cfg.map_capacity_log2))) return bail(r);
     if ((r = graph_scratch_alloc(c->gs, c->N))) return bail(fail(c, r, "graph scratch allocation failed"));
     c->gworker.start(device);
+    c->fworker.start(device);
     if (hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream) != hipSuccess) return bail(SGS_EHIP);
     launch_map_clear(c->stream, c->map.v, c->st);
     for (int k = 0; k < 8; ++k)
@@ -835,7 +844,9 @@ void sgs_destroy(sgs_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     c->gworker.wait_idle();
+    c->fworker.wait_idle();
     c->gworker.stop();
+    c->fworker.stop();
     if (c->streamF) hipStreamSynchronize(c->streamF);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) hipStreamSynchronize(c->stream2);
@@ -1231,13 +1242,14 @@ int sgs_prefetch_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *
     N.job_done.store(0, std::memory_order_relaxed);
     N.front_rc = SGS_OK;
     ScanSet *ps = &N;
+    const int slot = (int)(ps - c->sets);
     const bool graph = c->cfg.enable_graph != 0;
-    c->gworker.submit([c, ps, xyzi_dev, label_dev, n, is_kitti, graph] {
+    c->gworker.submit([c, ps, slot, xyzi_dev, label_dev, n, is_kitti, graph] {
         const FrontInput in{xyzi_dev, nullptr, label_dev, nullptr, n, is_kitti, false, {0, 0, 0, 0, 0, 0}};
         ps->front_rc = enqueue_front(c, *ps, in);
         ps->front_enqueued.store(1, std::memory_order_release);
-        if (graph && !ps->front_rc) graph_job(c, *ps, n);
-        ps->job_done.store(1, std::memory_order_release);
+        if (graph && !ps->front_rc) graph_enqueue_job(c, *ps, slot, n);  // hands over to the second helper
+        else ps->job_done.store(1, std::memory_order_release);
     });
     return SGS_OK;
 }

@@ -27,6 +27,17 @@ struct ClusterStat {
     int32_t count, first;             // points, smallest class-local point index
 };
 
+struct GraphSlot {
+    char *hostblk = nullptr;          // host-pinned, device-mapped block the kernels write their results into
+    char *hostblk_dev = nullptr;      // the same block as the device sees it
+    hipEvent_t ev_done = nullptr;     // recorded behind the last kernel enqueued for this slot
+    ClassParams params_host[5];
+    std::vector<float> last_desc;     // node descriptors of the scan
+    std::vector<int> box_perm;        // reference-order box -> device-order box
+    int enqueued_upper = 0;
+    bool enqueued_graph = false;
+};
+
 struct GraphScratch {
     int N = 0;
     int32_t *cat_blockcnt = nullptr;  // [nblocks][8]
@@ -49,14 +60,9 @@ struct GraphScratch {
     double *edge_dev = nullptr;       // [kMaxNodes^2]
     int32_t *hist_dev = nullptr;      // [kMaxNodes][3*subinterval]
     int32_t *n_boxes_dev = nullptr;   // node count for the edge kernel (0 when over kMaxNodes)
-    // host staging
-    ClassParams params_host[kNumFgClasses];
-    std::vector<float> last_desc;     // node descriptors of the last processed scan
-    std::vector<int> box_perm;        // reference-order box -> device-order box of the last scan
-    char *hostblk = nullptr;          // host-pinned, device-mapped block the kernels write their results into
-    char *hostblk_dev = nullptr;      // the same block as the device sees it
-    int enqueued_upper = 0;
-    bool enqueued_graph = false;
+    // host side of a scan's results: two slots, so the kernels of the next scan can be enqueued (and run)
+    // while the host still reads the previous scan's
+    GraphSlot slot[2];
 };
 
 constexpr int kMaxNodes = 1024;       // graph nodes (boxes) per scan
@@ -72,11 +78,13 @@ int graph_cluster(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n
                   std::vector<double> *boxes, int *n_boxes, int32_t *point_cluster_host, int *n_fg, int *n_bg,
                   std::string *err);
 // pipeline form: enqueue (kernels only, no host sync) early, finish (+ graph) after the ICP loop
-int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, int n_upper,
+// `slot` (0/1) selects the host result block; enqueue and finish of one scan use the same slot
+int graph_cluster_enqueue(hipStream_t s, GraphScratch &g, int slot, CloudView in, const int32_t *n_ptr, int n_upper,
                           const sgs_config &cfg, bool with_graph, std::string *err);
-int graph_cluster_finish(hipStream_t s, GraphScratch &g, const int32_t *n_ptr, std::vector<double> *boxes, int *n_boxes,
-                         int32_t *point_cluster_host, int *n_fg, int *n_bg, std::vector<int> *box_perm, std::string *err);
-int graph_finish_scan(hipStream_t s, GraphScratch &g, CloudView in, const int32_t *n_ptr, const sgs_config &cfg,
+int graph_cluster_finish(hipStream_t s, GraphScratch &g, int slot, const int32_t *n_ptr, std::vector<double> *boxes,
+                         int *n_boxes, int32_t *point_cluster_host, int *n_fg, int *n_bg, std::vector<int> *box_perm,
+                         std::string *err);
+int graph_finish_scan(hipStream_t s, GraphScratch &g, int slot, CloudView in, const int32_t *n_ptr, const sgs_config &cfg,
                       std::vector<double> *boxes, int *n_boxes, std::string *err);
 int graph_build(hipStream_t s, GraphScratch &g, const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
                 double subgraph_edge_th, float *desc, double *edge_matrix, double *eigenvalues, int32_t *edges,
