@@ -56,7 +56,15 @@ __device__ inline SearchConst search_const(const MapView &m) {
 // The wave is alone on its SIMD, so this is bound by instruction count as much as by memory
 // latency: everything per-voxel (slot, count, the query's fp32 position in that voxel's frame) is
 // computed once by the voxel's lane and fetched per candidate with ds_bpermute.
-__device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &sc, D3 w, int lane) {
+//
+// reach: a neighbour voxel whose BOX is farther from the query than `reach` cannot hold a point within
+// `reach`, and the callers drop a nearest neighbour that is not closer than their distance limit
+// (F/VoxelHashMap.cpp:120-125), so such voxels are neither probed nor scanned.  A voxel with key k
+// holds the coordinates c with trunc(c / voxel) == k: [k, k+1) * voxel for k > 0, (k-1, k] * voxel for
+// k < 0 and (-1, 1) * voxel for k == 0.  `reach` carries a millimetre of slack over the limit, far
+// above any fp32 rounding of the offsets.  When a nearest neighbour inside the limit exists its voxel
+// is always scanned, so results are unchanged; only the work is.
+__device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &sc, D3 w, int lane, float reach) {
     const K3 kc{voxel_coord_fast(w.x, m.voxel, sc.inv_voxel), voxel_coord_fast(w.y, m.voxel, sc.inv_voxel),
                 voxel_coord_fast(w.z, m.voxel, sc.inv_voxel)};
     int slot = -1;
@@ -69,7 +77,14 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
         relx = (float)(w.x - (double)kn.x * m.voxel);
         rely = (float)(w.y - (double)kn.y * m.voxel);
         relz = (float)(w.z - (double)kn.z * m.voxel);
-        if (key_in_range(kn)) {
+        const float vs = (float)m.voxel;
+        auto axis_gap = [vs](float rel, int k) {  // distance from the query to the voxel's extent along one axis
+            const float lo = k > 0 ? 0.f : -vs, hi = k < 0 ? 0.f : vs;
+            return fmaxf(fmaxf(lo - rel, rel - hi), 0.f);
+        };
+        const float gx = axis_gap(relx, kn.x), gy = axis_gap(rely, kn.y), gz = axis_gap(relz, kn.z);
+        const bool near_enough = gx * gx + (gy * gy + gz * gz) <= reach * reach;
+        if (near_enough && key_in_range(kn)) {
             const unsigned long long pk = pack_key(kn);
             uint32_t s = map_hash(pk) & m.mask;
             for (uint32_t step = 0; step <= m.mask; ++step) {
@@ -445,6 +460,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
     const double max_corr = st->max_corr, th = st->kernel_th;
     const SearchConst sc = search_const(m);
     const double max_corr2 = max_corr * max_corr, th2 = th * th;
+    const float reach = (float)max_corr + 1e-3f;
     double acc[kIcpSums];
 #pragma unroll
     for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
             p = D3{src.x[q], src.y[q], src.z[q]};
             label = src.l[q];
         }
-        const QueryResult r = wave_nearest(m, sc, s, lane);
+        const QueryResult r = wave_nearest(m, sc, s, lane, reach);
         acc[17] += (double)r.candidates;
         acc[18] += (double)r.probes;
         if (!r.found) continue;
@@ -549,9 +565,10 @@ __global__ __launch_bounds__(256) void correspondences_kernel(MapView m, CloudVi
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const SearchConst sc = search_const(m);
+    const float reach = (float)max_dist + 1e-3f;
     for (int q = blockIdx.x * 4 + wave; q < n; q += gridDim.x * 4) {
         const D3 s{src.x[q], src.y[q], src.z[q]};
-        const QueryResult r = wave_nearest(m, sc, s, lane);
+        const QueryResult r = wave_nearest(m, sc, s, lane, reach);
         bool ok = false;
         if (r.found) ok = sqrt(sq3(sub(r.target, s))) < max_dist;
         if (lane == 0) {
