@@ -98,7 +98,7 @@ typedef struct sgs_stats {
     uint32_t size;
     uint32_t reserved;
     int64_t scans;
-    int64_t icp_kernel_launches;   /* launches of the fused correspondence+reduction kernel */
+    int64_t icp_kernel_launches;   /* launches of the Gauss-Newton kernel (one per registration, or one per iteration) */
     double icp_kernel_ms_total;    /* HIP-event time of those launches (context stream) */
     int64_t icp_queries_total;     /* source points processed by those launches */
     int64_t icp_candidates_total;  /* resident candidate points examined */
@@ -106,6 +106,7 @@ typedef struct sgs_stats {
     int64_t map_insert_cas_retries;
     int64_t map_rehashes;
     double stage_ms[8]; /* summed HIP-event ms: 0 preprocess, 1 downsample, 2 icp, 3 map update, 4 cluster+graph */
+    int64_t icp_fallbacks;         /* registrations repeated with one launch per iteration (one-launch loop gave up) */
 } sgs_stats;
 
 /* ---- lifecycle ---- */

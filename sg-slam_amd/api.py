@@ -65,7 +65,7 @@ class SgsStats(ctypes.Structure):
         ("size", u32), ("reserved", u32), ("scans", i64), ("icp_kernel_launches", i64),
         ("icp_kernel_ms_total", c_dbl), ("icp_queries_total", i64), ("icp_candidates_total", i64),
         ("icp_probes_total", i64), ("map_insert_cas_retries", i64), ("map_rehashes", i64),
-        ("stage_ms", c_dbl * 8),
+        ("stage_ms", c_dbl * 8), ("icp_fallbacks", i64),
     ]
 
 

@@ -526,6 +526,170 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
     if (wave == 0) solve_and_update(st, ts, S, solve_lds, lane, mirror);
 }
 
+// ---- the whole Gauss-Newton loop in ONE launch -------------------------------------------------------
+// Every block keeps its queries, publishes its partial sums, waits until all blocks of the iteration
+// have published (one monotonic counter: arrive = agent-scope add, wait = sc1-load poll by one lane),
+// then folds ALL partials itself and runs the solve itself: every block ends up with the same new pose,
+// bit for bit, so nothing has to be broadcast back and the next iteration starts at once.  Against one
+// launch per iteration this drops the dispatch, the state reload, the host's polling and the launches
+// that run past convergence.
+// Residency: the wait needs all kIcpBlocks blocks to become resident.  They are 4-wave blocks, several
+// fit a CU, and kernels of other streams finish without waiting for this one, so they do; should a poll
+// nevertheless run out (many contexts on one GPU), the block raises the abort bit in the counter, every
+// block leaves, and the host repeats the registration with one launch per iteration.
+constexpr uint32_t kAbortBit = 1u << 30;
+constexpr uint32_t kSpinLimit = 1u << 21;
+
+__global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, CloudView src, int src_cap,
+                                                                     const int32_t *__restrict__ n_ptr, DevState *st,
+                                                                     double *partials2 /*two [kIcpSums][kIcpBlocks] buffers*/,
+                                                                     HostMirror *mirror) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int waves_per_block = kIcpThreads / 64;
+    const int q0 = blockIdx.x * waves_per_block + wave;
+    const int qs = q0 < src_cap ? q0 : src_cap - 1;
+    const D3 p0{src.x[qs], src.y[qs], src.z[qs]};  // the wave's first (usually only) query stays in registers
+    const int label0 = src.l[qs];
+    const int n = *n_ptr;
+    Rigid T_icp = st->T_icp, T_total = st->T_total;
+    const double max_corr = st->max_corr, th = st->kernel_th;
+    const int max_iter = st->icp_max_iter;
+    const SearchConst sc = search_const(m);
+    const double max_corr2 = max_corr * max_corr, th2 = th * th;
+    const float reach = (float)max_corr + 1e-3f;
+    long long corr = 0, cand = 0, probe = 0;
+    __shared__ double red[kIcpThreads / 64][kIcpSums];
+    __shared__ double S[kIcpSums];
+    __shared__ SolveLds solve_lds;
+    __shared__ Rigid s_T[2];
+    __shared__ int s_flag;  // after the wait: 1 = abort; after the solve: 1 = converged
+    int it = 0;
+    bool done = false;
+    while (it < max_iter) {
+        double acc[kIcpSums];
+#pragma unroll
+        for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
+        D3 p = p0;
+        int label = label0;
+        int q = q0;
+        while (q < n) {
+            const D3 s = apply(T_total, p);
+            const int lab = label;
+            q += gridDim.x * waves_per_block;
+            if (q < n) {
+                p = D3{src.x[q], src.y[q], src.z[q]};
+                label = src.l[q];
+            }
+            const QueryResult r = wave_nearest(m, sc, s, lane, reach);
+            acc[17] += (double)r.candidates;
+            acc[18] += (double)r.probes;
+            if (!r.found) continue;
+            const D3 res = sub(s, r.target);
+            const double r2 = sq3(res);
+            if (!(r2 < max_corr2)) continue;
+            const double wgt = th2 / ((th + r2) * (th + r2));
+            const double ws = wgt * semantic_weight(lab);
+            acc[0] += wgt;
+            acc[1] += wgt * s.x; acc[2] += wgt * s.y; acc[3] += wgt * s.z;
+            acc[4] += wgt * s.x * s.x; acc[5] += wgt * s.y * s.y; acc[6] += wgt * s.z * s.z;
+            acc[7] += wgt * s.x * s.y; acc[8] += wgt * s.x * s.z; acc[9] += wgt * s.y * s.z;
+            acc[10] += ws * res.x; acc[11] += ws * res.y; acc[12] += ws * res.z;
+            const D3 sxr = crs(s, res);
+            acc[13] += ws * sxr.x; acc[14] += ws * sxr.y; acc[15] += ws * sxr.z;
+            acc[16] += 1.0;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < kIcpSums; ++k) red[wave][k] = acc[k];
+        }
+        __syncthreads();
+        // partials alternate between two buffers: a block can be at most one iteration ahead of another
+        double *buf = partials2 + (size_t)(it & 1) * kIcpSums * kIcpBlocks;
+        if (wave == 0) {
+            if (lane < kIcpSums) {
+                double sum = 0.0;
+#pragma unroll
+                for (int w = 0; w < kIcpThreads / 64; ++w) sum += red[w][lane];
+                __hip_atomic_store(&buf[(size_t)lane * gridDim.x + blockIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the arrival
+            if (lane == 0) {
+                __hip_atomic_fetch_add(&st->icp_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t target = (uint32_t)(it + 1) * gridDim.x;
+                int abort = 0;
+                for (uint32_t spins = 0;; ++spins) {
+                    const uint32_t t = __hip_atomic_load(&st->icp_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t >= target) {
+                        abort = t >= kAbortBit ? 1 : 0;
+                        break;
+                    }
+                    if (spins > kSpinLimit) {
+                        __hip_atomic_fetch_add(&st->icp_ticket, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        abort = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                s_flag = abort;
+            }
+        }
+        __syncthreads();
+        if (s_flag) {
+            if (threadIdx.x == 0 && mirror) __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        fold_partials<kIcpThreads / 64>(buf, S);
+        if (wave == 0) {
+            if (lane == 0) {
+                double b[6];
+                normal_equations(S, solve_lds.A, b);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) solve_lds.rhs[i] = -b[i];
+            }
+            wave_lds_sync();
+            wave_solve6(solve_lds, lane);
+            wave_lds_sync();
+            if (lane <= 1) {
+                double x[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) x[i] = solve_lds.x[i];
+                double nn = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
+                const Rigid est = rigid_exp_small(D3{x[0], x[1], x[2]}, D3{x[3], x[4], x[5]});
+                s_T[lane] = compose_fast(est, lane == 0 ? T_icp : T_total);  // [0] T_icp, [1] T_total
+                if (lane == 0) s_flag = (nn < 1e-8) ? 1 : 0;  // F/Registration.cpp:169
+            }
+        }
+        __syncthreads();
+        T_icp = s_T[0];
+        T_total = s_T[1];
+        corr += (long long)S[16];
+        cand += (long long)S[17];
+        probe += (long long)S[18];
+        ++it;
+        done = s_flag != 0;
+        if (done) break;
+        __syncthreads();  // S, s_T, s_flag and red are rewritten by the next iteration
+    }
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    st->T_icp = T_icp;
+    st->T_total = T_total;
+    st->icp_corr = corr; st->icp_cand = cand; st->icp_probe = probe;
+    st->icp_iter = it;
+    st->icp_done = 1;
+    if (mirror) {
+        mirror->n_in = st->n_in; mirror->n_c = st->n_c; mirror->n_d = st->n_d; mirror->n_s = st->n_s;
+        mirror->err_flags = st->err_flags;
+        mirror->pose[0] = T_total.qw; mirror->pose[1] = T_total.qx; mirror->pose[2] = T_total.qy; mirror->pose[3] = T_total.qz;
+        mirror->pose[4] = T_total.t.x; mirror->pose[5] = T_total.t.y; mirror->pose[6] = T_total.t.z;
+        mirror->icp_corr = corr; mirror->icp_cand = cand; mirror->icp_probe = probe;
+        __hip_atomic_store(&mirror->icp_iter, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mirror->icp_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ __launch_bounds__(256) void icp_finish_kernel(DevState *st, const double *partials, int nblocks,
                                                          double *__restrict__ out28) {
     __shared__ double S[kIcpSums];
@@ -590,6 +754,12 @@ void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap, 
                           double *partials, bool solve, HostMirror *mirror) {
     hipLaunchKernelGGL(icp_iteration_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st,
                        partials, solve ? 1 : 0, mirror);
+}
+
+void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
+                           double *partials2, HostMirror *mirror) {
+    hipLaunchKernelGGL(icp_persistent_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st, partials2,
+                       mirror);
 }
 
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out28_dev) {

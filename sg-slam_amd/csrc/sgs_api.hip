@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -178,6 +179,7 @@ struct sgs_ctx {
     Rigid model_deviation = rigid_identity();
     int map_live_host = 0, map_tomb_host = 0, map_points_host = 0;
     int prev_iters = 6;
+    bool icp_persistent = true;  // whole Gauss-Newton loop in one launch (SGS_ICP_PER_LAUNCH=1 in the environment: one launch per iteration)
     int last_n[5] = {0, 0, 0, 0, 0};
 
     // profiling
@@ -409,11 +411,8 @@ int enqueue_icp_iteration(sgs_ctx *c, CloudView src, const int32_t *n_ptr) {
     return SGS_OK;
 }
 
-int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const int32_t *sizes4, const Rigid &guess, double max_corr,
-            double kernel_th, int *iters_out) {
-    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4);
-    *iters_out = 0;
-    if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
+// one launch per Gauss-Newton iteration, a window of launches kept ahead of the last one seen to finish
+int run_icp_per_launch(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *iters_out) {
     volatile int32_t *mb = &c->mirror->icp_iter;  // [0] iterations finished, [1] done
     mb[0] = 0;
     mb[1] = 0;
@@ -442,14 +441,79 @@ int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const int32_t *size
             }
         }
     }
-    const int iters = __atomic_load_n(&mb[0], __ATOMIC_ACQUIRE);
+    *iters_out = __atomic_load_n(&mb[0], __ATOMIC_ACQUIRE);
+    return SGS_OK;
+}
+
+// the whole loop in one launch; *fell_back = true when its inter-block wait ran out and nothing was done
+int run_icp_persistent(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *iters_out, bool *fell_back) {
+    volatile int32_t *mb = &c->mirror->icp_iter;
+    mb[0] = 0;
+    mb[1] = 0;
+    __sync_synchronize();
+    *fell_back = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        if (c->icp_events_used == c->icp_events.size()) {
+            hipEvent_t a, b;
+            SGS_HIP(c, hipEventCreate(&a));
+            SGS_HIP(c, hipEventCreate(&b));
+            c->icp_events.emplace_back(a, b);
+        }
+        e0 = c->icp_events[c->icp_events_used].first;
+        e1 = c->icp_events[c->icp_events_used].second;
+        c->icp_events_used++;
+        SGS_HIP(c, hipEventRecord(e0, c->stream));
+    }
+    launch_icp_persistent(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, c->mirror_dev);
+    if (e1) SGS_HIP(c, hipEventRecord(e1, c->stream));
+    long spins = 0;
+    int done;
+    while (!(done = __atomic_load_n(&mb[1], __ATOMIC_ACQUIRE))) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFF) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                if (!(done = __atomic_load_n(&mb[1], __ATOMIC_ACQUIRE)))
+                    return fail(c, SGS_EHIP, "ICP kernel ended without reporting");
+                break;
+            } else if (q != hipErrorNotReady) {
+                return fail(c, SGS_EHIP, "ICP loop: %s", hipGetErrorString(q));
+            }
+        }
+    }
+    if (done == 2) {  // the kernel gave up waiting for its other blocks
+        SGS_HIP(c, hipStreamSynchronize(c->stream));
+        *fell_back = true;
+        c->stats.icp_fallbacks++;
+        if (c->profiling) c->icp_events_used--;
+        return SGS_OK;
+    }
+    *iters_out = __atomic_load_n(&mb[0], __ATOMIC_ACQUIRE);
+    return SGS_OK;
+}
+
+int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const int32_t *sizes4, const Rigid &guess, double max_corr,
+            double kernel_th, int *iters_out) {
+    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4);
+    *iters_out = 0;
+    if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
+    int iters = 0, r;
+    bool fell_back = !c->icp_persistent;
+    if (c->icp_persistent && (r = run_icp_persistent(c, src, n_ptr, &iters, &fell_back))) return r;
+    if (fell_back) {
+        if (c->icp_persistent) launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4);
+        if ((r = run_icp_per_launch(c, src, n_ptr, &iters))) return r;
+    }
     *iters_out = iters;
     c->prev_iters = iters;
     return SGS_OK;
 }
 
 void drain_icp_events(sgs_ctx *c, int iterations_run) {
-    // only the first `iterations_run` launches did work; later ones exited on the done flag
+    // per-launch mode: only the first `iterations_run` launches did work, later ones exited on the done
+    // flag; one-launch mode: the single event pair brackets the whole loop
+    if (c->icp_persistent && c->icp_events_used) iterations_run = (int)c->icp_events_used;
     for (size_t k = 0; k < c->icp_events_used; ++k) {
         float ms = 0.f;
         if ((int)k < iterations_run && hipEventElapsedTime(&ms, c->icp_events[k].first, c->icp_events[k].second) == hipSuccess) {
@@ -820,7 +884,11 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     if ((r = dev_alloc(c, &c->map_slot_of, N))) return bail(r);
     if ((r = dev_alloc(c, &c->map_next, N))) return bail(r);
     if ((r = dev_alloc(c, &c->map_blockstat, ((size_t)1 << 26) / 256))) return bail(r);
-    if ((r = dev_alloc(c, &c->partials, (size_t)kIcpBlocks * kIcpSums))) return bail(r);
+    if ((r = dev_alloc(c, &c->partials, 2 * (size_t)kIcpBlocks * kIcpSums))) return bail(r);
+    {
+        const char *e = getenv("SGS_ICP_PER_LAUNCH");
+        c->icp_persistent = !(e && e[0] == '1');
+    }
     if ((r = dev_alloc(c, &c->out28, 32))) return bail(r);
     if ((r = dev_alloc(c, &c->corr_tgt, N * 4))) return bail(r);
     if ((r = dev_alloc(c, &c->corr_found, N))) return bail(r);

@@ -132,6 +132,11 @@ void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max
 void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap /*elements allocated, >= 1*/,
                           const int32_t *n_ptr, DevState *st, double *partials, bool solve,
                           HostMirror *mirror /*host-mapped, nullable*/);
+// the whole Gauss-Newton loop in one launch (partials2: two partial buffers); leaves mirror->icp_done = 1,
+// or 2 when its inter-block wait ran out (then nothing was written and the caller repeats the loop with
+// launch_icp_iteration)
+void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
+                           double *partials2, HostMirror *mirror);
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
                             int32_t *found);
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out27_dev);

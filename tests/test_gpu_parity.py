@@ -488,6 +488,27 @@ def test_pipeline_prefetch_matches_serial():
         hip.hipFree(p)
 
 
+def test_icp_one_launch_loop_matches_launch_per_iteration():
+    """The whole Gauss-Newton loop in one launch (every block folds and solves for itself) against one
+    launch per iteration (last block folds and solves): same arithmetic in the same order."""
+    import os
+    a = make_ctx()
+    os.environ["SGS_ICP_PER_LAUNCH"] = "1"
+    try:
+        b = make_ctx()
+    finally:
+        del os.environ["SGS_ICP_PER_LAUNCH"]
+    for k in range(12):
+        xyzi, xyz, lab = _scan(k, "small")
+        ra, rb = a.process_scan_f32(xyzi, lab, None, ""), b.process_scan_f32(xyzi, lab, None, "")
+        assert ra["iterations"] == rb["iterations"], k
+        assert np.array_equal(ra["pose"], rb["pose"]), (k, ra["pose"] - rb["pose"])
+        assert ra["correspondences"] == rb["correspondences"] and ra["candidates"] == rb["candidates"]
+    assert a.stats().icp_fallbacks == 0
+    a.close()
+    b.close()
+
+
 def test_error_behaviour():
     ctx = make_ctx(max_points=1024)
     big = np.zeros((2000, 3))
