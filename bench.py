@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip instance clustering + graph (diagnostic only)")
     ap.add_argument("--cpu-max-scans", type=int, default=120)
+    ap.add_argument("--map-log2", type=int, default=19, help="initial voxel-map table size, log2 slots (grows by rehash)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not hand scan k+1 to sgs_prefetch_scan_f32_dev while scan k registers (default: do; the "
                          "front half of the next scan then overlaps the ICP of the current one)")
@@ -70,7 +71,7 @@ def main():
     torch.cuda.synchronize()
 
     def run_pass(profile):
-        cfg = api.preset("kitti", max_points=max(1 << 17, 1 << int(np.ceil(np.log2(n_pts)))), map_capacity_log2=19,
+        cfg = api.preset("kitti", max_points=max(1 << 17, 1 << int(np.ceil(np.log2(n_pts)))), map_capacity_log2=args.map_log2,
                          enable_graph=0 if args.no_graph else 1, async_map_update=0 if args.sync_map_update else 1)
         ctx = api.Context(cfg, device=local_rank)
         ctx.set_profiling(profile)
@@ -79,7 +80,7 @@ def main():
         counts = np.zeros((total, 6), dtype=np.int64)
 
         def step(i):
-            if not args.no_prefetch and i + 1 < total:
+            if not args.no_prefetch and not profile and i + 1 < total:  # the profiled pass stays serial: per-stage events
                 ctx.prefetch_scan_dev(d_scans[i + 1].data_ptr(), d_labels[i + 1].data_ptr(), n_pts, "")
             ctx.process_scan_dev(d_scans[i].data_ptr(), d_labels[i].data_ptr(), n_pts, None, "", res)
             poses[i] = res.pose[:]
@@ -102,15 +103,28 @@ def main():
     value = job_steps / elapsed
     tc = counts[W:]
     launches = max(1, st.icp_kernel_launches)
-    # algorithmic bytes of the fused correspondence + linear-system kernel (SURVEY.md 8d B_iter):
-    # per query 16 B point + 27 slot probes x 16 B + 16 B per resident candidate, + 27 x 8 B result
-    bytes_total = st.icp_queries_total * (16 + 27 * 16) + 16 * st.icp_candidates_total + launches * 27 * 8
+    # algorithmic bytes of the Gauss-Newton kernel (SURVEY.md 8d B_iter, with the probes and candidates the
+    # kernel really touches: voxels farther than the correspondence limit are skipped): per query and
+    # iteration a 28-B source point, 16 B per slot header probed, 16 B per resident candidate examined;
+    # per iteration and block 160 B of partial sums written and read once (that every block re-reads all
+    # of them is this implementation's choice, not the algorithm's: it shows up in `traffic`, not here)
+    iters_total = int(tc[:, 4].sum())
+    bytes_total = (st.icp_queries_total * 28 + 16 * st.icp_probes_total + 16 * st.icp_candidates_total
+                   + iters_total * 256 * 160 * 2)
     kern_s = st.icp_kernel_ms_total * 1e-3
     achieved = bytes_total / kern_s / 1e9 if kern_s > 0 else 0.0
+    # HBM traffic per launch of that kernel: rocprofv3 cannot run inside this process, so the number comes
+    # from the committed PMC passes of this same command (profiles/README.md, tools/pmc_traffic.py)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+            traffic = json.load(fh)["kernels"]["icp_persistent_kernel"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {
-        "bound": "hbm", "kernel": "icp_accumulate_kernel (27-neighbour correspondences + JtJ/Jtr reduction)",
+        "bound": "hbm", "kernel": "icp_persistent_kernel (whole Gauss-Newton loop of a scan: 27-neighbour correspondences + JtJ/Jtr reduction + 6x6 solve per iteration)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": None,
+        "traffic": traffic,
         "launches": int(st.icp_kernel_launches), "avg_launch_us": round(1e3 * st.icp_kernel_ms_total / launches, 3),
         "algorithmic_bytes_per_launch": int(bytes_total / launches),
         "profiled_pass_ms_per_step": round(1e3 * elapsed_p / K, 4),

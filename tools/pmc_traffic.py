@@ -1,0 +1,48 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one pass each, CSV output) per kernel and
+write profiles/<round>_pmc_traffic.json, which bench.py reads for roofline.traffic.
+
+  python tools/pmc_traffic.py gpurun_out/r1_pmc_fetch/f_counter_collection.csv \
+                              gpurun_out/r1_pmc_write/w_counter_collection.csv profiles/r1_pmc_traffic.json
+
+Units and corrections (MI355X_MICROARCH.md, HBM section): both counters are in KB; on gfx950 FETCH_SIZE
+tallies 128-B requests at 64 B, so fetched bytes = 2 x FETCH_SIZE; WRITE_SIZE is taken as is.
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        m = re.search(r"(\w+)\(", r["Kernel_Name"])
+        k = m.group(1) if m else r["Kernel_Name"]
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+    return {k: {"dispatches": n, "mean_kb": v / n} for k, (n, v) in agg.items()}
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(f) | set(w)):
+        fk, wk = f.get(k, {"dispatches": 0, "mean_kb": 0.0}), w.get(k, {"dispatches": 0, "mean_kb": 0.0})
+        kernels[k] = {
+            "dispatches": max(fk["dispatches"], wk["dispatches"]),
+            "fetch_size_kb_raw": round(fk["mean_kb"], 2),
+            "write_size_kb_raw": round(wk["mean_kb"], 2),
+            "hbm_bytes_per_launch": int(1024 * (2.0 * fk["mean_kb"] + wk["mean_kb"])),
+        }
+    json.dump({"correction": "bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE) (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
+               "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 10",
+               "kernels": kernels}, open(out, "w"), indent=1)
+    print(json.dumps(kernels.get("icp_persistent_kernel"), indent=1))
+
+
+if __name__ == "__main__":
+    main()
