@@ -78,11 +78,14 @@ def main():
         res = api.SgsScanResult()
         poses = np.zeros((total, 7))
         counts = np.zeros((total, 6), dtype=np.int64)
+        lat = np.zeros(total)
 
         def step(i):
             if not args.no_prefetch and not profile and i + 1 < total:  # the profiled pass stays serial: per-stage events
                 ctx.prefetch_scan_dev(d_scans[i + 1].data_ptr(), d_labels[i + 1].data_ptr(), n_pts, "")
+            t0 = time.perf_counter()
             ctx.process_scan_dev(d_scans[i].data_ptr(), d_labels[i].data_ptr(), n_pts, None, "", res)
+            lat[i] = time.perf_counter() - t0
             poses[i] = res.pose[:]
             counts[i] = (res.n_in, res.n_cluster, res.n_ds, res.n_src, res.icp_iterations, res.map_voxels)
 
@@ -92,13 +95,13 @@ def main():
         elapsed, job_steps = timed_steps(dist, lambda i: step(W + i), K, sync_fn=torch.cuda.synchronize)
         st = ctx.stats()
         ctx.close()
-        return elapsed, job_steps, st, poses, counts
+        return elapsed, job_steps, st, poses, counts, lat[W:]
 
-    elapsed, job_steps, st_clean, poses, counts = run_pass(profile=False)
+    elapsed, job_steps, st_clean, poses, counts, lat = run_pass(profile=False)
     # second, identical pass with HIP events around every launch of the dominant kernel (events are
     # recorded on the context's own stream); kept out of the headline timing because the event pairs
     # add host work per Gauss-Newton iteration.
-    elapsed_p, _, st, poses_p, _ = run_pass(profile=True)
+    elapsed_p, _, st, poses_p, _, _ = run_pass(profile=True)
 
     value = job_steps / elapsed
     tc = counts[W:]
@@ -150,7 +153,23 @@ def main():
                    "mean_candidates_per_query": round(st.icp_candidates_total / max(1, st.icp_queries_total), 2),
                    "mean_probes_per_query": round(st.icp_probes_total / max(1, st.icp_queries_total), 2)},
         "roofline": roofline,
+        # host-side latency of one sgs_process_scan_f32_dev call (pose + graph on the host when it returns)
+        "latency_ms": {"p50": round(1e3 * float(np.percentile(lat, 50)), 4), "p99": round(1e3 * float(np.percentile(lat, 99)), 4)},
     }
+    if rank == 0:
+        # achievable HBM bandwidth on this very GPU, same run: device-to-device copy of 1 GiB
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        roofline["hbm_copy_gbs_measured"] = round(5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a, b
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -173,7 +192,20 @@ def main():
             worst_t = max(worst_t, float(np.linalg.norm(d[4:])))
             worst_r = max(worst_r, float(2 * np.arctan2(np.linalg.norm(d[:3]), abs(d[3]))))
             ocounts.append((r["n_in"], r["n_cluster"], r["n_ds"], r["n_src"], r["iterations"], r["map_voxels"]))
+        # single-thread figure on a short sample
+        O.set_threads(1)
+        slam1 = O.Slam(O.kitti_config(enable_graph=0 if args.no_graph else 1))
+        t1 = 0.0
+        m1 = min(10, m)
+        for i in range(W + m1):
+            xyz = scans_host[i][:, :3].astype(np.float64)
+            t0 = time.perf_counter()
+            slam1.process(xyz, labels_host[i])
+            if i >= W:
+                t1 += time.perf_counter() - t0
+        O.set_threads(cores)
         out["cpu_baseline"] = {"value": round(m / t_cpu, 2), "unit": "scans/s", "cores": cores, "kind": "port",
+                               "one_thread_scans_per_s": round(m1 / t1, 2),
                                "sample": f"the same first {W}+{m} synthetic scans (warm-up + timed) through the oracle restatement, "
                                          f"OpenMP where the reference uses TBB; timed scans {W}..{W + m - 1}"}
         oc, gc = np.array(ocounts), counts[:W + m]
