@@ -166,6 +166,19 @@ int sgs_register_frame(sgs_ctx *ctx, const double *xyzl, int n, const double *in
                        double max_correspondence_distance, double kernel, double *out_pose7,
                        int *iterations);
 
+/* ---- voxel map sharded by key over ranks (BASELINE.json configs[4]; no counterpart in the reference, which
+ * has one map in one address space).  owner(voxel) = hash(kx >> block_log2, ky >> block_log2) % world; a rank
+ * stores the voxels it owns plus a one-voxel halo, so a query whose centre voxel it owns finds all 27
+ * neighbours locally and every correspondence is found by exactly one rank.  Call on an empty map; every rank
+ * then feeds the SAME points to sgs_map_update / sgs_map_add_points (each keeps its share). ---- */
+int sgs_shard_set(sgs_ctx *ctx, int rank, int world, int block_log2);
+/* Sums buf[0..count) over all ranks in place (e.g. an RCCL / gloo all-reduce); returns 0 on success. */
+typedef int (*sgs_allreduce_fn)(double *buf, int count, void *user);
+/* RegisterFrameSemantic (frontend/Registration.cpp:147-177) on the sharded map: per Gauss-Newton iteration one
+ * all-reduce of 28 doubles (21 of JtJ, 6 of Jtr, the correspondence count); every rank gets the same pose. */
+int sgs_register_frame_sharded(sgs_ctx *ctx, const double *xyzl, int n, const double *guess_pose7, double max_correspondence_distance,
+                               double kernel, sgs_allreduce_fn allreduce, void *user, double *out_pose7, int *iterations);
+
 /* ---- frontend/SemanticCluster.{hpp,cpp}, frontend/SemGraph.{hpp,cpp} ---- */
 /* ClusterPoints (SemanticCluster.cpp:205-360).  boxes: 8 doubles each
  * [cx,cy,cz, dx,dy,dz, label(1 vehicle/2 trunk/3 pole), points_num], in the reference's output order.

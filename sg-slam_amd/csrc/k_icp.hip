@@ -67,6 +67,12 @@ __device__ inline SearchConst search_const(const MapView &m) {
 __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &sc, D3 w, int lane, float reach) {
     const K3 kc{voxel_coord_fast(w.x, m.voxel, sc.inv_voxel), voxel_coord_fast(w.y, m.voxel, sc.inv_voxel),
                 voxel_coord_fast(w.z, m.voxel, sc.inv_voxel)};
+    if (m.shard_world > 1 && shard_owner(kc, m.shard_log2, m.shard_world) != m.shard_rank) {
+        // sharded map: the rank that owns the centre voxel answers this query (it holds all 27 neighbours)
+        QueryResult none;
+        none.found = false; none.target = D3{0, 0, 0}; none.label = 0; none.candidates = 0; none.probes = 0;
+        return none;
+    }
     int slot = -1;
     uint32_t cnt = 0;
     int probes = 0;
@@ -760,6 +766,16 @@ void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap,
                            double *partials2, HostMirror *mirror) {
     hipLaunchKernelGGL(icp_persistent_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st, partials2,
                        mirror);
+}
+
+namespace {
+__global__ void icp_set_pose_kernel(DevState *st, Rigid T_icp, Rigid T_total) {
+    st->T_icp = T_icp;
+    st->T_total = T_total;
+}
+}  // namespace
+void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const Rigid &T_total) {
+    hipLaunchKernelGGL(icp_set_pose_kernel, dim3(1), dim3(1), 0, s, st, T_icp, T_total);
 }
 
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out28_dev) {

@@ -52,6 +52,10 @@ __global__ __launch_bounds__(kBlock) void map_add_kernel(MapView m, CloudView in
         slot_of[i] = -1;
         return;
     }
+    if (m.shard_world > 1 && !shard_stores(k, m.shard_log2, m.shard_world, m.shard_rank)) {
+        slot_of[i] = -1;  // another rank's voxel, outside this rank's halo
+        return;
+    }
     const unsigned long long pk = pack_key(k);
     uint32_t s = map_hash(pk) & m.mask;
     int found = -1;

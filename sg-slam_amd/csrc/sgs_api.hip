@@ -32,7 +32,7 @@ struct CloudBuf {
 };
 
 struct MapBuf {
-    MapView v{nullptr, nullptr, nullptr, 0, 0, 0.0};
+    MapView v{nullptr, nullptr, nullptr, 0, 0, 0.0, 0, 1, 3};
     int log2cap = 0;
 };
 
@@ -179,6 +179,7 @@ struct sgs_ctx {
     Rigid model_deviation = rigid_identity();
     int map_live_host = 0, map_tomb_host = 0, map_points_host = 0;
     int prev_iters = 6;
+    int shard_rank = 0, shard_world = 1, shard_log2 = 3;  // key sharding of the map over ranks (sgs_shard_set)
     bool icp_persistent = true;  // whole Gauss-Newton loop in one launch (SGS_ICP_PER_LAUNCH=1 in the environment: one launch per iteration)
     int last_n[5] = {0, 0, 0, 0, 0};
 
@@ -251,6 +252,7 @@ int alloc_map(sgs_ctx *c, MapBuf *m, int log2cap) {
     m->v.mask = (uint32_t)(cap - 1);
     m->v.cap = c->cfg.max_points_per_voxel;
     m->v.voxel = c->cfg.voxel_size;
+    m->v.shard_rank = c->shard_rank; m->v.shard_world = c->shard_world; m->v.shard_log2 = c->shard_log2;
     m->log2cap = log2cap;
     return SGS_OK;
 }
@@ -1235,6 +1237,59 @@ int sgs_register_frame(sgs_ctx *c, const double *xyzl, int n, const double *gues
     if (c->profiling) drain_icp_events(c, iters);
     rigid_to_pose7(c->st_host->T_total, out_pose7);
     if (iterations) *iterations = iters;
+    return SGS_OK;
+}
+
+// ---- key-sharded map (BASELINE.json configs[4]) ----
+int sgs_shard_set(sgs_ctx *c, int rank, int world, int block_log2) {
+    ENTER(c);
+    if (world < 1 || rank < 0 || rank >= world || block_log2 < 0 || block_log2 > 16) return fail(c, SGS_EINVAL, "bad shard parameters");
+    if (c->map_live_host != 0) return fail(c, SGS_EINVAL, "the map must be empty when the sharding changes");
+    c->shard_rank = rank; c->shard_world = world; c->shard_log2 = block_log2;
+    c->map.v.shard_rank = rank; c->map.v.shard_world = world; c->map.v.shard_log2 = block_log2;
+    return SGS_OK;
+}
+
+// RegisterFrameSemantic (F/Registration.cpp:147-177) against a map that is sharded over ranks: every rank
+// holds the same source points and the voxels it owns (+ halo), reduces the queries whose centre voxel
+// it owns to the 27 scalars of JtJ / Jtr (+ count), `allreduce` sums the 28 doubles over the ranks, and
+// every rank solves the same 6x6 system and takes the same convergence decision - no broadcast.
+int sgs_register_frame_sharded(sgs_ctx *c, const double *xyzl, int n, const double *guess7, double max_corr, double kernel,
+                               sgs_allreduce_fn allreduce, void *user, double *out_pose7, int *iterations) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if ((n && !xyzl) || !guess7 || !out_pose7 || !allreduce) return fail(c, SGS_EINVAL, "null argument");
+    int r;
+    if ((r = upload_xyzl(c, xyzl, n, c->aux))) return r;  // aux_n[0] = n
+    const Rigid guess = rigid_from_pose7(guess7);
+    Rigid T_icp = rigid_identity(), T_total = guess;
+    launch_icp_init(c->stream, c->st, guess, max_corr, kernel, kIcpMaxIter, nullptr);
+    int it = 0;
+    double sys[28];
+    while (it < kIcpMaxIter) {
+        launch_icp_iteration(c->stream, c->map.v, c->aux, c->N, &c->aux_n[0], c->st, c->partials, false, nullptr);
+        launch_linear_system_finish(c->stream, c->st, c->partials, c->out28);
+        SGS_HIP(c, hipMemcpyAsync(sys, c->out28, sizeof(sys), hipMemcpyDeviceToHost, c->stream));
+        SGS_HIP(c, hipStreamSynchronize(c->stream));
+        if (allreduce(sys, 28, user) != 0) return fail(c, SGS_EINVAL, "the all-reduce callback failed");
+        double A[6][6], rhs[6], x[6];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) A[i][j] = A[j][i] = sys[k++];
+        for (int i = 0; i < 6; ++i) rhs[i] = -sys[k++];
+        solve6_static(A, rhs, x);
+        const Rigid est = rigid_exp(x);
+        T_icp = compose(est, T_icp);
+        T_total = compose(est, T_total);
+        launch_icp_set_pose(c->stream, c->st, T_icp, T_total);
+        ++it;
+        double nn = 0;
+        for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
+        if (nn < 1e-8) break;  // same test as solve_and_update (k_icp.hip)
+    }
+    SGS_HIP(c, hipStreamSynchronize(c->stream));
+    rigid_to_pose7(T_total, out_pose7);
+    if (iterations) *iterations = it;
     return SGS_OK;
 }
 

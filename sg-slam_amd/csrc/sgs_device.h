@@ -54,6 +54,9 @@ struct MapView {
     uint32_t mask;    // capacity - 1
     int32_t cap;      // max points per voxel
     double voxel;
+    // key sharding over ranks (shard_world <= 1: off): inserts keep owned + halo voxels only, the
+    // registration kernels skip queries whose centre voxel another rank owns
+    int32_t shard_rank = 0, shard_world = 1, shard_log2 = 3;
 };
 
 constexpr int kIcpSums = 20;  // 16 moment sums + n_corr + candidates + probes + spare
@@ -137,6 +140,7 @@ void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap /
 // launch_icp_iteration)
 void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
                            double *partials2, HostMirror *mirror);
+void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const Rigid &T_total);
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
                             int32_t *found);
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out27_dev);

@@ -329,6 +329,21 @@ SGS_HD uint32_t map_hash(uint64_t p) {
     p ^= p >> 33;
     return (uint32_t)p;
 }
+// Owner of a voxel when the map is sharded by key over `world` ranks (BASELINE.json configs[4], SURVEY.md
+// 8e row 2): coarse blocks of 2^b x 2^b voxel columns (z is not split), hashed to a rank.  Arithmetic shift =
+// floor division, so the blocks tile negative coordinates too.
+SGS_HD int shard_owner(K3 k, int block_log2, int world) {
+    const uint32_t bx = (uint32_t)(k.x >> block_log2), by = (uint32_t)(k.y >> block_log2);
+    return (int)(((bx * 73856093u) ^ (by * 19349663u)) % (uint32_t)world);
+}
+// a rank stores a voxel when it owns it or any of its neighbours (one-voxel halo): a query whose centre
+// voxel the rank owns then finds all 27 neighbour voxels locally
+SGS_HD bool shard_stores(K3 k, int block_log2, int world, int rank) {
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            if (shard_owner(K3{k.x + dx, k.y + dy, k.z}, block_log2, world) == rank) return true;
+    return false;
+}
 SGS_HD double semantic_weight(int label) {  // F/Registration.hpp:21-56
     if (label == 16 || label == 18 || label == 19) return 1.2;
     if (label >= 0 && label < 20) return 1.0;

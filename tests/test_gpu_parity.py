@@ -293,6 +293,103 @@ def test_register_frame_matches_oracle():
     ctx.close()
 
 
+# ---------------- map sharded by voxel key (BASELINE.json configs[4]) ----------------
+class _ThreadAllReduce:
+    """In-process stand-in for the all-reduce callback: `world` threads, one context each, lock-step sum."""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.bufs = world, [None] * world
+        self.bar = threading.Barrier(world, timeout=60)
+        self.calls = 0
+
+    def __call__(self, rank):
+        def reduce(a):
+            self.bufs[rank] = a.copy()
+            self.bar.wait()
+            total = np.sum(self.bufs, axis=0)  # same order on every rank -> same bits
+            self.bar.wait()
+            a[:] = total
+            if rank == 0:
+                self.calls += 1
+        return reduce
+
+
+@pytest.mark.parametrize("world,block_log2", [(2, 2), (3, 0), (4, 3)])
+def test_key_sharded_map_registers_like_one_map(world, block_log2):
+    import threading
+    from sg_slam_amd.shard import shard_owner, shard_stores
+    ctxs = [make_ctx() for _ in range(world)]
+    om = O.Map(1.0, 100.0, 20)
+    for r, c in enumerate(ctxs):
+        c.ShardSet(r, world, block_log2)
+    for k in (0, 1, 2):
+        _, xyz, lab = _scan(k)
+        px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
+        dx, dl, _, _ = O.voxel_downsample(px, pl, 0.5)
+        om.update(_xyzl(dx, dl), synth.gt_pose(k))
+        for c in ctxs:
+            c.Update(_xyzl(dx, dl), synth.gt_pose(k))  # every rank is fed the same points and keeps its share
+    # each rank holds exactly the voxels the host-side rule gives it, with the unsharded map's contents
+    ko, co, po = om.dump()
+    full = {tuple(k): (int(n), p[:n]) for k, n, p in zip(ko, co, po)}
+    for r, c in enumerate(ctxs):
+        kg, cg, pg = c.map_dump()
+        want = ko[shard_stores(ko, block_log2, world, r)]
+        assert sorted(map(tuple, kg)) == sorted(map(tuple, want))
+        for k, n, p in zip(kg, cg, pg):
+            fn, fp = full[tuple(k)]
+            assert n == fn and np.array_equal(p[:n, 3], fp[:, 3]) and np.abs(p[:n] - fp).max() < 1e-6  # voxel-local fp32 offsets
+    assert sum(int((shard_owner(ko, block_log2, world) == r).sum()) for r in range(world)) == len(ko)
+    sx, sl = _source(3)
+    q = _xyzl(sx, sl)
+    guess = O.se3_mul(synth.gt_pose(3), O.se3_exp([0.3, 0.05, 0.0, 0, 0, 0.01]))
+    po_, info = om.register_frame(q, guess, 6.0, 0.667)
+    ar = _ThreadAllReduce(world)
+    out = [None] * world
+
+    def run(r):
+        try:
+            out[r] = ctxs[r].RegisterFrameSharded(q, guess, 6.0, 0.667, ar(r))
+        except BaseException as e:  # noqa: BLE001 - reported below; a dead thread must not hang the others
+            out[r] = e
+            ar.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    for o in out:
+        assert not isinstance(o, BaseException), repr(o)
+    for pg, itg in out:
+        assert np.array_equal(pg, out[0][0]) and itg == out[0][1]  # every rank: the same pose, bit for bit
+    pg, itg = out[0]
+    et, er = pose_err(po_, pg)
+    assert et < POSE_TOL_M and er < POSE_TOL_RAD
+    assert et < 1e-6 and er < 1e-7
+    assert abs(itg - info["iterations"]) <= 1 and ar.calls == itg  # one all-reduce of 28 doubles per iteration
+    for c in ctxs:
+        c.close()
+
+
+def test_key_sharded_map_two_gloo_processes_one_gpu():
+    """Two processes (one context each, both on this GPU), torch.distributed gloo all-reduce as the callback."""
+    import json, os, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, SGS_TEST_OUT=d, OMP_NUM_THREADS="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29619", os.path.join(root, "tests", "_gpu_shard_worker.py")]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res = [json.load(open(os.path.join(d, f"gshard{k}.json"))) for k in range(2)]
+    a, b = res
+    assert a["pose"] == b["pose"] and a["iters"] == b["iters"]
+    et, er = pose_err(np.array(a["ref_pose"]), np.array(a["pose"]))
+    assert et < 1e-6 and er < 1e-7
+    assert abs(a["iters"] - a["ref_iters"]) <= 1
+    assert max(a["voxels"], b["voxels"]) < a["full_voxels"] <= a["voxels"] + b["voxels"]
+
+
 # ---------------- SemanticCluster / SemGraph ----------------
 @pytest.mark.parametrize("shape,frame", [("small", 3), ("small", 25), ("hdl64", 12), ("os1_64", 7), ("hdl64", 60)])
 def test_cluster_points_match_oracle(ctx_small, shape, frame):

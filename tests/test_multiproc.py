@@ -34,3 +34,21 @@ def test_two_gloo_ranks_time_is_max_over_ranks():
     assert res[0]["elapsed"] >= max(0.06, res[1]["own"] * 0.5)        # ... and it is the slow rank's
     assert res[0]["last_t"] != res[1]["last_t"]                       # independent streams (different seeds)
     assert sorted(res[0]["mine"] + res[1]["mine"]) == list(range(11))  # sequences dealt without overlap
+
+
+def test_two_gloo_ranks_key_sharded_map_registers_like_one_map():
+    """map sharded by voxel key, per-iteration all-reduce of the 28 Gauss-Newton scalars."""
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, SGS_TEST_OUT=d, OMP_NUM_THREADS="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29617", os.path.join(ROOT, "tests", "_gloo_shard_worker.py")]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res = [json.load(open(os.path.join(d, f"shard{k}.json"))) for k in range(2)]
+    a, b = res
+    assert a["pose"] == b["pose"] and a["iters"] == b["iters"]           # same sums -> same solve on every rank, bit for bit
+    assert a["counts"][0] + b["counts"][0] == a["counts"][1] == a["counts"][2]  # each correspondence found by exactly one rank
+    assert min(a["counts"][0], b["counts"][0]) > 0.2 * a["counts"][2]    # and the work is really split
+    assert abs(a["iters"] - a["ref_iters"]) <= 1
+    assert max(abs(x - y) for x, y in zip(a["pose"], a["ref_pose"])) < 1e-7  # summation order only
+    assert max(a["voxels"], b["voxels"]) < a["full_voxels"] <= a["voxels"] + b["voxels"]  # shares + halo
