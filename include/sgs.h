@@ -169,15 +169,15 @@ int sgs_register_frame(sgs_ctx *ctx, const double *xyzl, int n, const double *in
 /* ---- voxel map sharded by key over ranks (BASELINE.json configs[4]; no counterpart in the reference, which
  * has one map in one address space).  owner(voxel) = hash(kx >> block_log2, ky >> block_log2) % world; a rank
  * stores the voxels it owns plus a one-voxel halo, so a query whose centre voxel it owns finds all 27
- * neighbours locally and every correspondence is found by exactly one rank.  Call on an empty map; every rank
- * then feeds the SAME points to sgs_map_update / sgs_map_add_points (each keeps its share). ---- */
-int sgs_shard_set(sgs_ctx *ctx, int rank, int world, int block_log2);
-/* Sums buf[0..count) over all ranks in place (e.g. an RCCL / gloo all-reduce); returns 0 on success. */
+ * neighbours locally and every correspondence is found by exactly one rank.  Call on an empty map.  Every rank
+ * then makes the SAME calls with the SAME points (sgs_map_update / sgs_map_add_points keep the rank's share;
+ * sgs_register_frame and sgs_process_scan* run the Gauss-Newton loop of frontend/Registration.cpp:147-177 with
+ * one all-reduce of 28 doubles per iteration - 21 of JtJ, 6 of Jtr, the correspondence count - plus one of a
+ * single double per registration, the map's voxel count) and gets the same pose, bit for bit.  Map sizes,
+ * dumps and correspondences stay per rank.  world == 1 switches sharding off. ---- */
+/* Sums buf[0..count) over all ranks in place (an RCCL / gloo all-reduce); returns 0 on success. */
 typedef int (*sgs_allreduce_fn)(double *buf, int count, void *user);
-/* RegisterFrameSemantic (frontend/Registration.cpp:147-177) on the sharded map: per Gauss-Newton iteration one
- * all-reduce of 28 doubles (21 of JtJ, 6 of Jtr, the correspondence count); every rank gets the same pose. */
-int sgs_register_frame_sharded(sgs_ctx *ctx, const double *xyzl, int n, const double *guess_pose7, double max_correspondence_distance,
-                               double kernel, sgs_allreduce_fn allreduce, void *user, double *out_pose7, int *iterations);
+int sgs_shard_set(sgs_ctx *ctx, int rank, int world, int block_log2, sgs_allreduce_fn allreduce, void *user);
 
 /* ---- frontend/SemanticCluster.{hpp,cpp}, frontend/SemGraph.{hpp,cpp} ---- */
 /* ClusterPoints (SemanticCluster.cpp:205-360).  boxes: 8 doubles each

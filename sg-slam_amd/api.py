@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sgs_reset_stats", "sgs_set_profiling", "sgs_preprocess", "sgs_correct_kitti", "sgs_deskew",
     "sgs_voxel_keys", "sgs_voxel_downsample", "sgs_map_clear", "sgs_map_empty", "sgs_map_add_points",
     "sgs_map_update", "sgs_map_prune", "sgs_map_size", "sgs_map_pointcloud", "sgs_map_dump",
-    "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_shard_set", "sgs_register_frame_sharded", "sgs_cluster_points",
+    "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_shard_set", "sgs_cluster_points",
     "sgs_build_graph", "sgs_process_scan", "sgs_process_scan_f32", "sgs_process_scan_f32_dev", "sgs_prefetch_scan_f32_dev", "sgs_get_cloud",
     "sgs_get_boxes", "sgs_get_poses", "sgs_remap_labels",
 ]
@@ -116,8 +116,7 @@ def lib():
         L.sgs_map_get_correspondences.argtypes = [c_vp, c_vp, c_int, c_dbl, c_vp, c_vp, c_vp, c_int, c_vp]
         L.sgs_build_linear_system.argtypes = [c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]
         L.sgs_register_frame.argtypes = [c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, c_vp, c_vp]
-        L.sgs_shard_set.argtypes = [c_vp, c_int, c_int, c_int]
-        L.sgs_register_frame_sharded.argtypes = [c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, ALLREDUCE_FN, c_vp, c_vp, c_vp]
+        L.sgs_shard_set.argtypes = [c_vp, c_int, c_int, c_int, ALLREDUCE_FN, c_vp]
         L.sgs_cluster_points.argtypes = [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
         L.sgs_build_graph.argtypes = [c_vp, c_vp, c_int, c_dbl, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp,
                                       c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]
@@ -190,6 +189,9 @@ class Context:
     def _ck(self, r, allow_capacity=False):
         if r == SGS_OK or (allow_capacity and r == SGS_ECAPACITY):
             return r
+        failure = getattr(self, "_shard_failure", None)
+        if failure:  # the all-reduce callback raised: that is the error to report
+            raise failure.pop()
         raise SgsError(r, lib().sgs_last_error(self.h).decode())
 
     def set_profiling(self, on):
@@ -297,31 +299,23 @@ class Context:
                                           float(kernel), out.ctypes.data, ctypes.byref(it)))
         return out, it.value
 
-    # ---- map sharded by voxel key over ranks (include/sgs.h: sgs_shard_set / sgs_register_frame_sharded) ----
-    def ShardSet(self, rank, world, block_log2=3):
-        self._ck(lib().sgs_shard_set(self.h, int(rank), int(world), int(block_log2)))
-
-    def RegisterFrameSharded(self, xyzl, initial_guess, max_correspondence_distance, kernel, allreduce):
-        """`allreduce(a)` sums the float64 array `a` (28 values) over all ranks IN PLACE, e.g.
-        ``lambda a: dist.all_reduce(torch.from_numpy(a))``; every rank must call with the same points."""
-        p = _f64(xyzl); g = _f64(initial_guess); out = np.empty(7); it = c_int()
-        failure = []
+    # ---- map sharded by voxel key over ranks (include/sgs.h: sgs_shard_set) ----
+    def ShardSet(self, rank, world, block_log2=3, allreduce=None):
+        """`allreduce(a)` sums the float64 numpy array `a` over all ranks IN PLACE (sg_slam_amd.shard.torch_allreduce
+        does it with torch.distributed); afterwards every rank makes the same calls with the same points."""
+        self._shard_failure = []
 
         def _cb(buf, count, _user):
             try:
                 allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
                 return 0
             except BaseException as e:  # an exception must not unwind through the C frames
-                failure.append(e)
+                self._shard_failure.append(e)
                 return 1
 
-        cb = ALLREDUCE_FN(_cb)
-        rc = lib().sgs_register_frame_sharded(self.h, p.ctypes.data, len(p), g.ctypes.data, float(max_correspondence_distance),
-                                              float(kernel), cb, None, out.ctypes.data, ctypes.byref(it))
-        if failure:
-            raise failure[0]
-        self._ck(rc)
-        return out, it.value
+        cb = ALLREDUCE_FN(_cb) if allreduce is not None else ctypes.cast(None, ALLREDUCE_FN)
+        self._ck(lib().sgs_shard_set(self.h, int(rank), int(world), int(block_log2), cb, None))
+        self._shard_cb = cb  # the library keeps the pointer: keep the thunk alive
 
     # ---- SemanticCluster / SemGraph ----
     def ClusterPoints(self, frame, label, deltaA, deltaR, deltaP, max_boxes=4096):

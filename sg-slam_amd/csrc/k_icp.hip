@@ -769,13 +769,15 @@ void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap,
 }
 
 namespace {
-__global__ void icp_set_pose_kernel(DevState *st, Rigid T_icp, Rigid T_total) {
+__global__ void icp_set_pose_kernel(DevState *st, Rigid T_icp, Rigid T_total, int iter, long long corr) {
     st->T_icp = T_icp;
     st->T_total = T_total;
+    st->icp_iter = iter;
+    st->icp_corr = corr;
 }
 }  // namespace
-void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const Rigid &T_total) {
-    hipLaunchKernelGGL(icp_set_pose_kernel, dim3(1), dim3(1), 0, s, st, T_icp, T_total);
+void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const Rigid &T_total, int iter, long long corr) {
+    hipLaunchKernelGGL(icp_set_pose_kernel, dim3(1), dim3(1), 0, s, st, T_icp, T_total, iter, corr);
 }
 
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out28_dev) {

@@ -180,6 +180,8 @@ struct sgs_ctx {
     int map_live_host = 0, map_tomb_host = 0, map_points_host = 0;
     int prev_iters = 6;
     int shard_rank = 0, shard_world = 1, shard_log2 = 3;  // key sharding of the map over ranks (sgs_shard_set)
+    sgs_allreduce_fn shard_allreduce = nullptr;
+    void *shard_user = nullptr;
     bool icp_persistent = true;  // whole Gauss-Newton loop in one launch (SGS_ICP_PER_LAUNCH=1 in the environment: one launch per iteration)
     int last_n[5] = {0, 0, 0, 0, 0};
 
@@ -495,10 +497,50 @@ int run_icp_persistent(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *ite
     return SGS_OK;
 }
 
+// Gauss-Newton loop against a map that is sharded by key over ranks (sgs_shard_set): every rank holds the
+// same source points and the voxels it owns (+ halo), reduces the queries whose centre voxel it owns to the
+// 27 scalars of JtJ / Jtr (+ the count), the caller's all-reduce sums the 28 doubles over the ranks, and every
+// rank solves the same 6x6 system and takes the same convergence decision - nothing is broadcast.
+int run_icp_sharded(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const Rigid &guess, int *iters_out) {
+    double live = (double)c->map_live_host;  // F/Registration.cpp:152 asks whether the WHOLE map is empty
+    if (c->shard_allreduce(&live, 1, c->shard_user) != 0) return fail(c, SGS_EINVAL, "the all-reduce callback failed");
+    if (live == 0.0) return SGS_OK;
+    Rigid T_icp = rigid_identity(), T_total = guess;
+    int it = 0;
+    long long corr = 0;
+    double sys[28];
+    while (it < kIcpMaxIter) {
+        launch_icp_iteration(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, false, nullptr);
+        launch_linear_system_finish(c->stream, c->st, c->partials, c->out28);
+        SGS_HIP(c, hipMemcpyAsync(sys, c->out28, sizeof(sys), hipMemcpyDeviceToHost, c->stream));
+        SGS_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->shard_allreduce(sys, 28, c->shard_user) != 0) return fail(c, SGS_EINVAL, "the all-reduce callback failed");
+        double A[6][6], rhs[6], x[6];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) A[i][j] = A[j][i] = sys[k++];
+        for (int i = 0; i < 6; ++i) rhs[i] = -sys[k++];
+        corr += (long long)sys[27];
+        solve6_static(A, rhs, x);
+        const Rigid est = rigid_exp(x);
+        T_icp = compose(est, T_icp);
+        T_total = compose(est, T_total);
+        ++it;
+        launch_icp_set_pose(c->stream, c->st, T_icp, T_total, it, corr);
+        double nn = 0;
+        for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
+        if (nn < 1e-8) break;  // same test as solve_and_update (k_icp.hip)
+    }
+    *iters_out = it;
+    c->prev_iters = it;
+    return SGS_OK;
+}
+
 int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const int32_t *sizes4, const Rigid &guess, double max_corr,
             double kernel_th, int *iters_out) {
     launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4);
     *iters_out = 0;
+    if (c->shard_world > 1) return run_icp_sharded(c, src, n_ptr, guess, iters_out);
     if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
     int iters = 0, r;
     bool fell_back = !c->icp_persistent;
@@ -687,7 +729,7 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     // in the host mirror by the kernel that ended the ICP loop, so the call returns while the update
     // runs and the next scan's preprocessing is queued behind it (same stream, so the next ICP sees the
     // updated map).  Needs an ICP loop that ran (not the first scan of a sequence).
-    const bool async = cfg.async_map_update != 0 && iters > 0 && !c->profiling;
+    const bool async = cfg.async_map_update != 0 && iters > 0 && !c->profiling && c->shard_world == 1;
     DevState hs;  // host view of the device state for this scan
     if (async) {
         const HostMirror &mi = *c->mirror;
@@ -1241,55 +1283,14 @@ int sgs_register_frame(sgs_ctx *c, const double *xyzl, int n, const double *gues
 }
 
 // ---- key-sharded map (BASELINE.json configs[4]) ----
-int sgs_shard_set(sgs_ctx *c, int rank, int world, int block_log2) {
+int sgs_shard_set(sgs_ctx *c, int rank, int world, int block_log2, sgs_allreduce_fn allreduce, void *user) {
     ENTER(c);
     if (world < 1 || rank < 0 || rank >= world || block_log2 < 0 || block_log2 > 16) return fail(c, SGS_EINVAL, "bad shard parameters");
+    if (world > 1 && !allreduce) return fail(c, SGS_EINVAL, "a sharded map needs the all-reduce callback");
     if (c->map_live_host != 0) return fail(c, SGS_EINVAL, "the map must be empty when the sharding changes");
     c->shard_rank = rank; c->shard_world = world; c->shard_log2 = block_log2;
+    c->shard_allreduce = allreduce; c->shard_user = user;
     c->map.v.shard_rank = rank; c->map.v.shard_world = world; c->map.v.shard_log2 = block_log2;
-    return SGS_OK;
-}
-
-// RegisterFrameSemantic (F/Registration.cpp:147-177) against a map that is sharded over ranks: every rank
-// holds the same source points and the voxels it owns (+ halo), reduces the queries whose centre voxel
-// it owns to the 27 scalars of JtJ / Jtr (+ count), `allreduce` sums the 28 doubles over the ranks, and
-// every rank solves the same 6x6 system and takes the same convergence decision - no broadcast.
-int sgs_register_frame_sharded(sgs_ctx *c, const double *xyzl, int n, const double *guess7, double max_corr, double kernel,
-                               sgs_allreduce_fn allreduce, void *user, double *out_pose7, int *iterations) {
-    ENTER(c);
-    CHECK_N(c, n);
-    if ((n && !xyzl) || !guess7 || !out_pose7 || !allreduce) return fail(c, SGS_EINVAL, "null argument");
-    int r;
-    if ((r = upload_xyzl(c, xyzl, n, c->aux))) return r;  // aux_n[0] = n
-    const Rigid guess = rigid_from_pose7(guess7);
-    Rigid T_icp = rigid_identity(), T_total = guess;
-    launch_icp_init(c->stream, c->st, guess, max_corr, kernel, kIcpMaxIter, nullptr);
-    int it = 0;
-    double sys[28];
-    while (it < kIcpMaxIter) {
-        launch_icp_iteration(c->stream, c->map.v, c->aux, c->N, &c->aux_n[0], c->st, c->partials, false, nullptr);
-        launch_linear_system_finish(c->stream, c->st, c->partials, c->out28);
-        SGS_HIP(c, hipMemcpyAsync(sys, c->out28, sizeof(sys), hipMemcpyDeviceToHost, c->stream));
-        SGS_HIP(c, hipStreamSynchronize(c->stream));
-        if (allreduce(sys, 28, user) != 0) return fail(c, SGS_EINVAL, "the all-reduce callback failed");
-        double A[6][6], rhs[6], x[6];
-        int k = 0;
-        for (int i = 0; i < 6; ++i)
-            for (int j = i; j < 6; ++j) A[i][j] = A[j][i] = sys[k++];
-        for (int i = 0; i < 6; ++i) rhs[i] = -sys[k++];
-        solve6_static(A, rhs, x);
-        const Rigid est = rigid_exp(x);
-        T_icp = compose(est, T_icp);
-        T_total = compose(est, T_total);
-        launch_icp_set_pose(c->stream, c->st, T_icp, T_total);
-        ++it;
-        double nn = 0;
-        for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
-        if (nn < 1e-8) break;  // same test as solve_and_update (k_icp.hip)
-    }
-    SGS_HIP(c, hipStreamSynchronize(c->stream));
-    rigid_to_pose7(T_total, out_pose7);
-    if (iterations) *iterations = it;
     return SGS_OK;
 }
 

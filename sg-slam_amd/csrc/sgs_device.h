@@ -140,7 +140,7 @@ void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap /
 // launch_icp_iteration)
 void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
                            double *partials2, HostMirror *mirror);
-void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const Rigid &T_total);
+void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const Rigid &T_total, int iter, long long corr);
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
                             int32_t *found);
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out27_dev);

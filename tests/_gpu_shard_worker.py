@@ -24,7 +24,7 @@ def xyzl(x, l):
 
 
 ctx = make_ctx()
-ctx.ShardSet(dist.rank, dist.world, 2)
+ctx.ShardSet(dist.rank, dist.world, 2, torch_allreduce)
 om = O.Map(1.0, 100.0, 20)
 for k in range(3):
     xyzi, raw, lab = synth.scan(k, "small")
@@ -38,7 +38,7 @@ dx, dl, _, _ = O.voxel_downsample(px, pl, 0.5)
 sx, sl, _, _ = O.voxel_downsample(dx, dl, 1.5)
 guess = O.se3_mul(synth.gt_pose(3), O.se3_exp([0.3, 0.05, 0.0, 0, 0, 0.01]))
 ref_pose, info = om.register_frame(xyzl(sx, sl), guess, 6.0, 0.667)
-pose, iters = ctx.RegisterFrameSharded(xyzl(sx, sl), guess, 6.0, 0.667, torch_allreduce)
+pose, iters = ctx.RegisterFrameSemantic(xyzl(sx, sl), guess, 6.0, 0.667)
 out = {"rank": dist.rank, "pose": [float(v) for v in pose], "ref_pose": [float(v) for v in ref_pose], "iters": int(iters),
        "ref_iters": int(info["iterations"]), "voxels": int(ctx.map_size()[0]), "full_voxels": int(om.size()[0])}
 with open(os.path.join(os.environ["SGS_TEST_OUT"], f"gshard{dist.rank}.json"), "w") as f:
