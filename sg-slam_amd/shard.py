@@ -45,3 +45,23 @@ def torch_allreduce(a):
         t.copy_(d.cpu())
     else:
         dist.all_reduce(t)
+
+
+class TorchAllReduce:
+    """The same, with the device bounce buffer of the RCCL case allocated once (28 doubles per call)."""
+
+    def __init__(self, local_rank=0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.dev = torch.empty(32, dtype=torch.float64, device=f"cuda:{local_rank}") if dist.get_backend() == "nccl" else None
+
+    def __call__(self, a):
+        t = self.torch.from_numpy(a)
+        if self.dev is None:
+            self.dist.all_reduce(t)
+        else:
+            d = self.dev[:len(a)]
+            d.copy_(t)
+            self.dist.all_reduce(d)
+            t.copy_(d)  # blocking D2H: the sums are in `a` when this returns
