@@ -665,3 +665,24 @@ def test_error_behaviour():
     bad = api.preset("kitti", max_points_per_voxel=0)
     h = api.c_vp()
     assert api.lib().sgs_create(api.ctypes.byref(bad), 0, api.ctypes.byref(h)) == api.SGS_EINVAL
+
+
+# ---------------- KITTI-layout sequence driver + trajectory score ----------------
+def test_sequence_from_disk_scores_like_the_oracle_run(tmp_path):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_sequence
+    from sg_slam_amd import kitti_io, trajectory
+    run_sequence.make_synthetic(str(tmp_path), 30, "small")
+    lidar, labels = str(tmp_path / "velodyne"), str(tmp_path / "labels")
+    hip_poses, _ = run_sequence.run(lidar, labels, "", str(tmp_path / "hip.txt"))
+    slam = O.Slam(O.kitti_config())
+    ora_poses, _ = run_sequence.run(lidar, labels, "", str(tmp_path / "ora.txt"),
+                                    step=lambda xyzi, lab, ts: slam.process(xyzi[:, :3].astype(np.float64), lab)["pose"])
+    assert len(hip_poses) == len(ora_poses) == 30  # stops at the first missing label file
+    gt = kitti_io.read_kitti_poses(str(tmp_path / "poses.txt"))
+    a = trajectory.evaluate(gt, kitti_io.read_kitti_poses(str(tmp_path / "hip.txt")))
+    b = trajectory.evaluate(gt, kitti_io.read_kitti_poses(str(tmp_path / "ora.txt")))
+    assert abs(a["Absolute Trajectory Error (m)"] - b["Absolute Trajectory Error (m)"]) < 1e-6
+    assert abs(a["Absolute Rotation Error (deg)"] - b["Absolute Rotation Error (deg)"]) < 1e-5
+    assert np.abs(hip_poses[:, :3, 3] - ora_poses[:, :3, 3]).max() < POSE_TOL_M
