@@ -166,6 +166,16 @@ int sgs_register_frame(sgs_ctx *ctx, const double *xyzl, int n, const double *in
                        double max_correspondence_distance, double kernel, double *out_pose7,
                        int *iterations);
 
+/* ---- loop-pair refinement: FastIcp::get_trans (loopclosure/FastIcp.cpp:205-220; FastIcp.hpp:51-58,91-92;
+ * its only caller LoopClosure.cpp:69-70 passes voxel_size_map = map_voxel_size_loop, cap 5 and the gate 0.5 m).
+ * Builds a private voxel map from cloud B (voxel size held in a float as the reference holds it, at most
+ * max_points_per_voxel points per voxel), registers cloud A against it from init_pose (unit weights: no robust
+ * kernel, no class weight; <= 500 iterations, stop at |update| < 1e-4) and returns T with T * A ~ B.  An empty
+ * cloud B returns init_pose (FastIcp.cpp:184).  The odometry map of the context is left untouched. ---- */
+int sgs_fast_icp(sgs_ctx *ctx, const double *xyzl_a, int n_a, const double *xyzl_b, int n_b, const double *init_pose7,
+                 float voxel_size_map, int max_points_per_voxel, double max_correspondence_distance, double *out_pose7,
+                 int *iterations);
+
 /* ---- voxel map sharded by key over ranks (BASELINE.json configs[4]; no counterpart in the reference, which
  * has one map in one address space).  owner(voxel) = hash(kx >> block_log2, ky >> block_log2) % world; a rank
  * stores the voxels it owns plus a one-voxel halo, so a query whose centre voxel it owns finds all 27

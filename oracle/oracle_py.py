@@ -80,6 +80,8 @@ def lib():
         L.sgo_build_linear_system.argtypes = [c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp]
         L.sgo_register_frame.restype = None
         L.sgo_register_frame.argtypes = [c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, c_vp, c_vp]
+        L.sgo_fast_icp.restype = None
+        L.sgo_fast_icp.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, ctypes.c_float, c_int, c_dbl, c_vp, c_vp]
         L.sgo_voxel_keys.restype = None
         L.sgo_voxel_keys.argtypes = [c_vp, c_int, c_dbl, c_vp]
         L.sgo_preprocess.argtypes = [c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]
@@ -281,6 +283,14 @@ class Map:
         lib().sgo_register_frame(self.h, xyzl.ctypes.data, len(xyzl), g.ctypes.data, float(max_corr),
                                  float(kernel), out.ctypes.data, info.ctypes.data)
         return out, dict(iterations=int(info[0]), candidates=int(info[1]), correspondences=int(info[2]))
+
+
+def fast_icp(xyzl_a, xyzl_b, init7, voxel_size_map=1.0, max_points_per_voxel=5, max_corr=0.5):
+    """loopclosure/FastIcp.cpp:205-220 get_trans: map <- cloud B, register cloud A; -> (pose7, info)."""
+    a = _f64(xyzl_a); b = _f64(xyzl_b); g = _f64(init7); out = np.empty(7); info = np.zeros(3, dtype=np.int64)
+    lib().sgo_fast_icp(a.ctypes.data, len(a), b.ctypes.data, len(b), g.ctypes.data, float(voxel_size_map),
+                       int(max_points_per_voxel), float(max_corr), out.ctypes.data, info.ctypes.data)
+    return out, dict(iterations=int(info[0]), candidates=int(info[1]), correspondences=int(info[2]))
 
 
 def cluster_points(xyz, label, dA, dR, dP, max_boxes=4096):

@@ -203,6 +203,15 @@ void sgo_register_frame(void *h, const double *xyzl, int n, const double *guess7
     if (info3) { info3[0] = info.iterations; info3[1] = info.candidates; info3[2] = info.correspondences; }
 }
 
+void sgo_fast_icp(const double *xyzl_a, int na, const double *xyzl_b, int nb, const double *init7, float voxel_size_map,
+                  int max_points_per_voxel, double max_corr, double *out_pose7, int64_t *info3) {
+    IcpInfo info;
+    const SE3 T = fast_icp_get_trans(p4_in(xyzl_a, na), p4_in(xyzl_b, nb), pose_in(init7), voxel_size_map,
+                                     max_points_per_voxel, max_corr, &info);
+    pose_out(T, out_pose7);
+    if (info3) { info3[0] = info.iterations; info3[1] = info.candidates; info3[2] = info.correspondences; }
+}
+
 // ---- clustering / graph ----
 // boxes: nb * 8 doubles [cx,cy,cz,dx,dy,dz,label,points_num]; point_cluster: n (cluster id per point, 0 if not foreground)
 int sgo_cluster_points(const double *xyz, const int32_t *label, int n, double dA, double dR, double dP,

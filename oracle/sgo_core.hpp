@@ -306,8 +306,9 @@ struct LinearSystem {
 
 // ---- frontend/Registration.cpp:71-113 AlignClouds (the reduction part) ------------------------
 // J = [I | -hat(s)], w = th^2/(th+|r|^2)^2, JTJ += J^T w J, JTr += J^T w r * w_sem(label).
+// plain = the loop-closure variant (loopclosure/FastIcp.cpp:137-170): no robust kernel, no class weight.
 inline LinearSystem build_linear_system(const std::vector<P4> &src, const std::vector<P4> &tgt,
-                                        double th) {
+                                        double th, bool plain = false) {
     const long n = (long)src.size();
     const int nt = omp_get_max_threads();
     std::vector<LinearSystem> part((size_t)nt);
@@ -326,8 +327,8 @@ inline LinearSystem build_linear_system(const std::vector<P4> &src, const std::v
             for (int a = 0; a < 3; ++a)
                 for (int b = 0; b < 3; ++b) J[a][3 + b] = -1.0 * H.m[a][b];
             const double r2 = sqnorm(r);
-            const double w = (th * th) / ((th + r2) * (th + r2));
-            const double ws = semantic_weight(label);
+            const double w = plain ? 1.0 : (th * th) / ((th + r2) * (th + r2));
+            const double ws = plain ? 1.0 : semantic_weight(label);
             const double rv[3] = {r.x, r.y, r.z};
             for (int a = 0; a < 6; ++a) {
                 for (int b = 0; b < 6; ++b) {
@@ -366,7 +367,7 @@ struct IcpInfo {
 };
 inline SE3 register_frame_semantic(const std::vector<P4> &frame, const VoxelHashMap &map,
                                    const SE3 &initial_guess, double max_corr, double kernel,
-                                   IcpInfo *info) {
+                                   IcpInfo *info, bool plain = false) {
     if (map.Empty()) return initial_guess;
     std::vector<P4> source = frame;
     auto transform = [](const SE3 &T, std::vector<P4> &pts) {
@@ -379,7 +380,7 @@ inline SE3 register_frame_semantic(const std::vector<P4> &frame, const VoxelHash
     SE3 T_icp;
     for (int j = 0; j < 500; ++j) {
         const Correspondences c = map.GetCorrespondences(source, max_corr);
-        const SE3 est = solve_linear_system(build_linear_system(c.src, c.tgt, kernel));
+        const SE3 est = solve_linear_system(build_linear_system(c.src, c.tgt, kernel, plain));
         transform(est, source);
         T_icp = est * T_icp;
         if (info) {
@@ -390,6 +391,19 @@ inline SE3 register_frame_semantic(const std::vector<P4> &frame, const VoxelHash
         if (norm6(se3_log(est)) < 0.0001) break;
     }
     return T_icp * initial_guess;
+}
+
+// ---- loopclosure/FastIcp.{hpp,cpp}: loop-pair refinement ----------------------
+// A private copy of the map + ICP above with four differences: the voxel size is held in a FLOAT
+// (FastIcp.hpp:91, so keys are trunc(p / (double)(float)size), FastIcp.cpp:35,49-51), the per-voxel cap is
+// the constructor's (5 at the only call site, LoopClosure.cpp:69), AlignClouds has no robust kernel and no
+// class weight (FastIcp.cpp:146-152), and the gate is the caller's 0.5 m (FastIcp.cpp:215).  get_trans
+// (FastIcp.cpp:205-220): map <- cloud B, register cloud A from the initial transform.
+inline SE3 fast_icp_get_trans(const std::vector<P4> &cloud_a, const std::vector<P4> &cloud_b, const SE3 &init,
+                              float voxel_size_map, int max_points_per_voxel, double max_corr, IcpInfo *info) {
+    VoxelHashMap map((double)voxel_size_map, 0.0, max_points_per_voxel);
+    map.AddPoints(cloud_b);
+    return register_frame_semantic(cloud_a, map, init, max_corr, 0.0, info, true);
 }
 
 // ---- frontend/Threshold.{hpp,cpp} -------------------------------------------------------------

@@ -466,6 +466,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
     const double max_corr = st->max_corr, th = st->kernel_th;
     const SearchConst sc = search_const(m);
     const double max_corr2 = max_corr * max_corr, th2 = th * th;
+    const bool plain = th < 0.0;  // no robust kernel, no class weight (loopclosure/FastIcp.cpp:146-152)
     const float reach = (float)max_corr + 1e-3f;
     double acc[kIcpSums];
 #pragma unroll
@@ -487,8 +488,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
         // |res| < max_corr (F/VoxelHashMap.cpp:120-125) compared in squares: differs from the
         // reference's sqrt form only for a residual within an ulp of the limit
         if (!(r2 < max_corr2)) continue;
-        const double wgt = th2 / ((th + r2) * (th + r2));
-        const double ws = wgt * semantic_weight(lab);
+        const double wgt = plain ? 1.0 : th2 / ((th + r2) * (th + r2));
+        const double ws = plain ? 1.0 : wgt * semantic_weight(lab);
         acc[0] += wgt;
         acc[1] += wgt * s.x; acc[2] += wgt * s.y; acc[3] += wgt * s.z;
         acc[4] += wgt * s.x * s.x; acc[5] += wgt * s.y * s.y; acc[6] += wgt * s.z * s.z;
@@ -563,6 +564,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     const int max_iter = st->icp_max_iter;
     const SearchConst sc = search_const(m);
     const double max_corr2 = max_corr * max_corr, th2 = th * th;
+    const bool plain = th < 0.0;  // no robust kernel, no class weight (loopclosure/FastIcp.cpp:146-152)
     const float reach = (float)max_corr + 1e-3f;
     long long corr = 0, cand = 0, probe = 0;
     __shared__ double red[kIcpThreads / 64][kIcpSums];
@@ -594,8 +596,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
             const D3 res = sub(s, r.target);
             const double r2 = sq3(res);
             if (!(r2 < max_corr2)) continue;
-            const double wgt = th2 / ((th + r2) * (th + r2));
-            const double ws = wgt * semantic_weight(lab);
+            const double wgt = plain ? 1.0 : th2 / ((th + r2) * (th + r2));
+            const double ws = plain ? 1.0 : wgt * semantic_weight(lab);
             acc[0] += wgt;
             acc[1] += wgt * s.x; acc[2] += wgt * s.y; acc[3] += wgt * s.z;
             acc[4] += wgt * s.x * s.x; acc[5] += wgt * s.y * s.y; acc[6] += wgt * s.z * s.z;

@@ -167,6 +167,9 @@ struct sgs_ctx {
     // state
     DevState *st = nullptr;
     DevState *st_host = nullptr;  // pinned
+    // second map + state of the loop-pair refinement (sgs_fast_icp), allocated at its first call
+    MapBuf loop_map;
+    DevState *st_loop = nullptr;
     // cluster / graph
     GraphScratch gs;
     GraphWorker gworker;  // launches: front half of prefetched scans, cluster / graph kernels
@@ -974,6 +977,7 @@ void sgs_destroy(sgs_ctx *c) {
     if (c->stream2) hipStreamDestroy(c->stream2);
     for (void *p : c->allocs) hipFree(p);
     free_map(&c->map);
+    free_map(&c->loop_map);
     graph_scratch_free(c->gs);
     if (c->st_host) hipHostFree(c->st_host);
     for (auto &e : c->icp_events) {
@@ -1280,6 +1284,76 @@ int sgs_register_frame(sgs_ctx *c, const double *xyzl, int n, const double *gues
     rigid_to_pose7(c->st_host->T_total, out_pose7);
     if (iterations) *iterations = iters;
     return SGS_OK;
+}
+
+// ---- loop-pair refinement: loopclosure/FastIcp.cpp:205-220 get_trans ----
+// The same kernels with another parameterisation: a second voxel map (float-held voxel size, cap per voxel from
+// the caller, no pruning) is filled with cloud B, cloud A is registered against it with unit weights
+// (kernel_th < 0 selects them in the kernels) and the caller's gate.  While it runs, the context's map, device
+// state and the config values the map code reads are swapped for the loop pair's and put back afterwards.
+namespace {
+struct LoopSwap {
+    sgs_ctx *c;
+    MapBuf map;
+    DevState *st;
+    int live, tomb, points, prev_iters, world, cap;
+    double voxel;
+    LoopSwap(sgs_ctx *c_, double voxel_, int cap_) : c(c_) {
+        map = c->map; st = c->st;
+        live = c->map_live_host; tomb = c->map_tomb_host; points = c->map_points_host;
+        prev_iters = c->prev_iters; world = c->shard_world; cap = c->cfg.max_points_per_voxel; voxel = c->cfg.voxel_size;
+        c->map = c->loop_map; c->st = c->st_loop;
+        c->loop_map = MapBuf{};  // owned by c->map while swapped
+        c->map_live_host = c->map_tomb_host = c->map_points_host = 0;
+        c->shard_world = 1;
+        c->cfg.max_points_per_voxel = cap_; c->cfg.voxel_size = voxel_;
+    }
+    ~LoopSwap() {
+        c->loop_map = c->map;  // may have been rebuilt larger
+        c->map = map; c->st = st;
+        c->map_live_host = live; c->map_tomb_host = tomb; c->map_points_host = points;
+        c->prev_iters = prev_iters; c->shard_world = world;
+        c->cfg.max_points_per_voxel = cap; c->cfg.voxel_size = voxel;
+        // the sweep of the loop map left ITS census in the host mirror: put the odometry map's back
+        c->mirror->map_live = live; c->mirror->map_tomb = tomb; c->mirror->map_points = points;
+    }
+};
+}  // namespace
+
+int sgs_fast_icp(sgs_ctx *c, const double *xyzl_a, int na, const double *xyzl_b, int nb, const double *init_pose7,
+                 float voxel_size_map, int max_points_per_voxel, double max_correspondence_distance, double *out_pose7,
+                 int *iterations) {
+    ENTER(c);
+    CHECK_N(c, na);
+    CHECK_N(c, nb);
+    if ((na && !xyzl_a) || (nb && !xyzl_b) || !init_pose7 || !out_pose7) return fail(c, SGS_EINVAL, "null argument");
+    if (!(voxel_size_map > 0.f) || max_points_per_voxel < 1 || max_points_per_voxel > 255)
+        return fail(c, SGS_EINVAL, "bad loop map parameters");
+    int r;
+    if (!c->st_loop) {
+        if ((r = dev_alloc(c, &c->st_loop, 1))) return r;
+        SGS_HIP(c, hipMemsetAsync(c->st_loop, 0, sizeof(DevState), c->stream));
+    }
+    const double voxel = (double)voxel_size_map;  // FastIcp.hpp:91 holds it in a float; the keys divide by that value
+    LoopSwap swap(c, voxel, max_points_per_voxel);
+    if (!c->map.v.slots || c->map.v.cap != max_points_per_voxel) {
+        free_map(&c->map);
+        int log2 = 12;
+        while (((long)nb) * 4 > (1L << log2)) ++log2;
+        if ((r = alloc_map(c, &c->map, log2))) return r;
+    }
+    c->map.v.voxel = voxel;
+    launch_map_clear(c->stream, c->map.v, c->st);
+    if ((r = map_add_common(c, xyzl_b, nb, nullptr, false))) return r;  // grows the table when nb needs it
+    int iters = 0;
+    const Rigid init = rigid_from_pose7(init_pose7);
+    if ((r = upload_xyzl(c, xyzl_a, na, c->aux))) return r;  // aux_n[0] = na
+    if ((r = run_icp(c, c->aux, &c->aux_n[0], nullptr, init, max_correspondence_distance, -1.0, &iters))) return r;
+    if ((r = sync_state(c))) return r;
+    if (c->profiling) drain_icp_events(c, iters);
+    rigid_to_pose7(c->st_host->T_total, out_pose7);
+    if (iterations) *iterations = iters;
+    return check_err_flags(c, c->st_host->err_flags);
 }
 
 // ---- key-sharded map (BASELINE.json configs[4]) ----

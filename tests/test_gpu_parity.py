@@ -686,3 +686,45 @@ def test_sequence_from_disk_scores_like_the_oracle_run(tmp_path):
     assert abs(a["Absolute Trajectory Error (m)"] - b["Absolute Trajectory Error (m)"]) < 1e-6
     assert abs(a["Absolute Rotation Error (deg)"] - b["Absolute Rotation Error (deg)"]) < 1e-5
     assert np.abs(hip_poses[:, :3, 3] - ora_poses[:, :3, 3]).max() < POSE_TOL_M
+
+
+# ---------------- FastIcp::get_trans, the loop-pair refinement ----------------
+@pytest.mark.parametrize("voxel,cap,ka,kb", [(1.0, 5, 6, 3), (0.8, 5, 30, 28), (0.5, 3, 12, 12)])
+def test_fast_icp_matches_oracle(ctx_small, voxel, cap, ka, kb):
+    def cloud(k):
+        _, xyz, lab = _scan(k)
+        px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
+        dx, dl, _, _ = O.voxel_downsample(px, pl, 0.5)
+        return _xyzl(dx, dl)
+    A, B = cloud(ka), cloud(kb)
+    rel = O.se3_mul(O.se3_inv(synth.gt_pose(kb)), synth.gt_pose(ka))  # A's frame in B's
+    init = O.se3_mul(rel, O.se3_exp([0.15, -0.1, 0.02, 0.002, -0.001, 0.01]))
+    before = ctx_small.map_size()
+    pg, itg = ctx_small.FastIcpGetTrans(A, B, init, voxel, cap, 0.5)
+    po, info = O.fast_icp(A, B, init, voxel, cap, 0.5)
+    et, er = pose_err(po, pg)
+    assert et < 1e-6 and er < 1e-7, (et, er)
+    assert abs(itg - info["iterations"]) <= 1 and itg >= 2
+    assert ctx_small.map_size() == before  # the odometry map is not touched
+    # a wider gate changes the answer in both the same way (the gate is the caller's)
+    pg2, _ = ctx_small.FastIcpGetTrans(A, B, init, voxel, cap, 2.0)
+    po2, _ = O.fast_icp(A, B, init, voxel, cap, 2.0)
+    et, er = pose_err(po2, pg2)
+    assert et < 1e-6 and er < 1e-7
+    # empty target cloud: the initial transform comes back (FastIcp.cpp:184)
+    pg3, it3 = ctx_small.FastIcpGetTrans(A, np.zeros((0, 4)), init, voxel, cap, 0.5)
+    assert it3 == 0 and np.allclose(pg3, init, atol=1e-15)
+
+
+def test_fast_icp_leaves_the_odometry_pipeline_alone():
+    a, b = make_ctx(), make_ctx()
+    scans = [_scan(k) for k in range(6)]
+    for k, (_, xyz, lab) in enumerate(scans):
+        ra = a.mainProcess(xyz, lab)
+        if k in (2, 4):  # a loop-pair refinement between two scans of the running sequence
+            A = _xyzl(*O.preprocess(scans[k][1], scans[k][2], 100.0, 5.0))[::7]
+            B = _xyzl(*O.preprocess(scans[k - 1][1], scans[k - 1][2], 100.0, 5.0))[::5]
+            a.FastIcpGetTrans(A, B, O.se3_exp([1.0, 0, 0, 0, 0, 0.004]), 1.0, 5, 0.5)
+        rb = b.mainProcess(xyz, lab)
+        assert np.array_equal(ra["pose"], rb["pose"]) and ra["map_voxels"] == rb["map_voxels"]
+    a.close(); b.close()

@@ -393,3 +393,29 @@ def test_graph_sub_triangles_sorted_float_sides():
         s = sorted(np.float32(x) for x in (np.linalg.norm(c[0] - c[m]), np.linalg.norm(c[0] - c[n]), np.linalg.norm(c[m] - c[n])))
         exp.append([float(x) for x in s])
     assert np.allclose(t0, exp, atol=0)
+
+
+def test_fast_icp_recovers_a_known_transform_and_uses_unit_weights():
+    """loopclosure/FastIcp.cpp: B is a point lattice, A the same points seen from a displaced frame."""
+    rng = np.random.default_rng(3)
+    g = np.stack(np.meshgrid(np.arange(-10, 10, 1.3), np.arange(-10, 10, 1.3), np.arange(-2, 3, 1.1), indexing="ij"), -1).reshape(-1, 3)
+    B = np.concatenate([g + rng.normal(size=g.shape) * 0.05, rng.integers(0, 26, (len(g), 1))], axis=1)
+    T = O.se3_exp([0.12, -0.08, 0.03, 0.004, -0.002, 0.01])
+    A = B.copy()
+    A[:, :3] = O.se3_act(O.se3_inv(T), B[:, :3])
+    pose, info = O.fast_icp(A, B, O.se3_exp([0, 0, 0, 0, 0, 0]), 1.0, 5, 0.5)
+    assert np.abs(pose - T).max() < 1e-9 and 2 <= info["iterations"] < 20
+    assert info["correspondences"] >= len(B)  # every point pairs with itself in every iteration
+    # labels play no role (no class weight): relabelling everything as an "ignored" class changes nothing
+    A2, B2 = A.copy(), B.copy()
+    A2[:, 3] = 25; B2[:, 3] = 0
+    pose2, _ = O.fast_icp(A2, B2, O.se3_exp([0, 0, 0, 0, 0, 0]), 1.0, 5, 0.5)
+    assert np.array_equal(pose, pose2)
+    # the voxel size is held in a float: 0.8f != 0.8, a point at 4 * 0.8 lands in voxel 3 of the float grid
+    assert int(3.2 / float(np.float32(0.8))) == 3 and int(3.2 / 0.8) == 4
+    # cap 1 keeps only the first point of a voxel
+    two = np.array([[0.1, 0.1, 0.1, 1], [0.6, 0.6, 0.6, 1]])
+    q = np.array([[0.62, 0.6, 0.6, 1.0]])
+    p_cap1, i1 = O.fast_icp(q, two, O.se3_exp([0] * 6), 1.0, 1, 2.0)
+    p_cap5, i5 = O.fast_icp(q, two, O.se3_exp([0] * 6), 1.0, 5, 2.0)
+    assert abs(p_cap5[4] + 0.02) < 1e-9 and abs(p_cap1[4] + 0.52) < 1e-9
