@@ -166,6 +166,18 @@ int sgs_register_frame(sgs_ctx *ctx, const double *xyzl, int n, const double *in
                        double max_correspondence_distance, double kernel, double *out_pose7,
                        int *iterations);
 
+/* ---- scan descriptor for the back-end: GenScanDescriptors (loopclosure/LoopClosure.cpp:15-32) = GenGraphDescriptors
+ * (:93-140: six label-pair histograms of edge length + three instance counts) followed by GenBackDescriptors
+ * (:145-188: per-ring occupancy of building / road points over 24 rings x 360 sectors, 5..50 m, sectors by
+ * fastAtan2 :438-457), each part and the whole L2-normalised in float.  6 * subinterval + 3 + 48 floats (231 with
+ * the defaults).  As in the reference a scan without building and road points yields NaN (no zero guard at :182-186).
+ * sgs_scan_descriptor: for the scan sgs_process_scan* handled last (its boxes and its 0.2 m cluster cloud, still on
+ * the device); sgs_gen_scan_descriptor: for boxes (nb x 8 doubles as sgs_cluster_points returns them) and the cloud
+ * ClusterPoints was given. ---- */
+int sgs_scan_descriptor(sgs_ctx *ctx, float *desc, int cap, int *n);
+int sgs_gen_scan_descriptor(sgs_ctx *ctx, const double *boxes, int nb, const double *xyz, const int32_t *label, int n,
+                            double edge_dis_th, int subinterval, float *desc, int cap, int *n_out);
+
 /* ---- loop-pair refinement: FastIcp::get_trans (loopclosure/FastIcp.cpp:205-220; FastIcp.hpp:51-58,91-92;
  * its only caller LoopClosure.cpp:69-70 passes voxel_size_map = map_voxel_size_loop, cap 5 and the gate 0.5 m).
  * Builds a private voxel map from cloud B (voxel size held in a float as the reference holds it, at most

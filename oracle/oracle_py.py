@@ -82,6 +82,9 @@ def lib():
         L.sgo_register_frame.argtypes = [c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, c_vp, c_vp]
         L.sgo_fast_icp.restype = None
         L.sgo_fast_icp.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, ctypes.c_float, c_int, c_dbl, c_vp, c_vp]
+        L.sgo_scan_descriptor.argtypes = [c_vp, c_int, c_vp, c_vp, c_int, c_dbl, c_int, c_vp]
+        L.sgo_fast_atan2.restype = c_dbl
+        L.sgo_fast_atan2.argtypes = [c_dbl, c_dbl]
         L.sgo_voxel_keys.restype = None
         L.sgo_voxel_keys.argtypes = [c_vp, c_int, c_dbl, c_vp]
         L.sgo_preprocess.argtypes = [c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]
@@ -291,6 +294,19 @@ def fast_icp(xyzl_a, xyzl_b, init7, voxel_size_map=1.0, max_points_per_voxel=5, 
     lib().sgo_fast_icp(a.ctypes.data, len(a), b.ctypes.data, len(b), g.ctypes.data, float(voxel_size_map),
                        int(max_points_per_voxel), float(max_corr), out.ctypes.data, info.ctypes.data)
     return out, dict(iterations=int(info[0]), candidates=int(info[1]), correspondences=int(info[2]))
+
+
+def scan_descriptor(boxes, xyz, label, edge_dis_th=60.0, subinterval=30):
+    """loopclosure/LoopClosure.cpp:15-32 GenScanDescriptors on the boxes + the 0.2 m cluster cloud of a scan."""
+    boxes = _f64(boxes).reshape(-1, 8); xyz = _f64(xyz); label = _i32(label)
+    out = np.empty(6 * subinterval + 3 + 48, dtype=np.float32)
+    n = lib().sgo_scan_descriptor(boxes.ctypes.data, len(boxes), xyz.ctypes.data, label.ctypes.data, len(xyz),
+                                  float(edge_dis_th), int(subinterval), out.ctypes.data)
+    return out[:n]
+
+
+def fast_atan2(y, x):
+    return float(lib().sgo_fast_atan2(float(y), float(x)))
 
 
 def cluster_points(xyz, label, dA, dR, dP, max_boxes=4096):

@@ -244,6 +244,17 @@ static std::vector<Bbox> boxes_in(const double *boxes, int nb) {
 }
 // desc: nb*(3*subinterval+dim) floats; edge_matrix nb*nb; evals nb; edges: up to max_edges pairs;
 // tri_counts nb (number of sub-triangles per node); triangles: concatenated 3 doubles each (max_tri)
+// GenScanDescriptors: boxes nb*8 as below, the 0.2 m cluster cloud; out: 6*subinterval + 3 + 48 floats
+int sgo_scan_descriptor(const double *boxes, int nb, const double *xyz, const int32_t *label, int n, double edge_dis_th,
+                        int subinterval, float *out) {
+    Cloud c;
+    c.p = vec3_in(xyz, n);
+    c.l.assign(label, label + n);
+    const std::vector<float> d = gen_scan_descriptors(boxes_in(boxes, nb), c, edge_dis_th, subinterval);
+    std::memcpy(out, d.data(), sizeof(float) * d.size());
+    return (int)d.size();
+}
+double sgo_fast_atan2(double y, double x) { return fast_atan2_deg(y, x); }
 int sgo_build_graph(const double *boxes, int nb, double edge_dis_th, int subinterval, int dim,
                     double subgraph_edge_th, float *desc, double *edge_matrix, double *evals,
                     int max_edges, int32_t *edges, double *edge_value, double *edge_weights,

@@ -12,6 +12,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <numeric>
@@ -717,6 +718,130 @@ inline Graph build_graph(const std::vector<Bbox> &boxes, double edge_dis_th, int
     }
     g.edge_matrix = Edge;
     return g;
+}
+
+// ---- loopclosure/LoopClosure.{hpp,cpp}: scan descriptor handed to the back-end -------
+// fastAtan2 (LoopClosure.cpp:438-457, constants LoopClosure.hpp:38-41: FLOAT literals times 180/pi in double),
+// degrees in [0, 360].
+inline double fast_atan2_deg(double y, double x) {
+    const double k = (double)(180 / 3.1415926535897932384626433832795);
+    const double p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k, p5 = 0.1555786518463281f * k,
+                 p7 = -0.04432655554792128f * k;
+    const double ax = std::abs(x), ay = std::abs(y);
+    double a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (double)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (double)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+inline float float_dot_self(const std::vector<float> &v) {  // std::inner_product(..., 0.0f): float accumulator
+    float acc = 0.0f;
+    for (float x : v) acc = acc + x * x;
+    return acc;
+}
+// GenGraphDescriptors (LoopClosure.cpp:93-140): 6 label-pair histograms of edge length + 3 instance counts
+inline std::vector<float> gen_graph_descriptors(const Graph &g, double edge_dis_th, int subinterval) {
+    const float siv = float(edge_dis_th / subinterval);
+    std::vector<float> d((size_t)subinterval * 6 + 3, 0.f);
+    for (size_t i = 0; i < g.edges.size(); ++i) {
+        const int a = g.node_labels[(size_t)g.edges[i].first], b = g.node_labels[(size_t)g.edges[i].second];
+        const int bin = int(g.edge_value[i] / siv) + 3;
+        int blk = -1;
+        if (a == 1 && b == 1) blk = 0;
+        else if (a == 2 && b == 2) blk = 1;
+        else if (a == 3 && b == 3) blk = 2;
+        else if ((a == 3 && b == 2) || (a == 2 && b == 3)) blk = 3;
+        else if ((a == 1 && b == 2) || (a == 2 && b == 1)) blk = 4;
+        else if ((a == 1 && b == 3) || (a == 3 && b == 1)) blk = 5;
+        if (blk >= 0) d[(size_t)(subinterval * blk + bin)]++;
+    }
+    const double ss_edge = float_dot_self(d);
+    float n_edge = float(std::sqrt(ss_edge));
+    if (n_edge == 0) n_edge = 0.000001f;
+    for (float &x : d) x /= n_edge;
+    float n_cnt = float(std::sqrt(g.vehicle_num * g.vehicle_num + g.trunk_num * g.trunk_num + g.pole_like_num * g.pole_like_num));
+    if (n_cnt == 0) n_cnt = 0.000001f;
+    d[0] = ((float)g.vehicle_num) / n_cnt;
+    d[1] = ((float)g.trunk_num) / n_cnt;
+    d[2] = ((float)g.pole_like_num) / n_cnt;
+    const float ss_all = float_dot_self(d);
+    float n_all = float(std::sqrt(ss_all));
+    if (n_all == 0) n_all = 0.000001f;
+    for (float &x : d) x /= n_all;
+    return d;
+}
+// GenBackDescriptors (LoopClosure.cpp:145-188): ring x sector occupancy (24 x 360, 5..50 m) of building (13) and
+// road (9) points, summed per ring, L2-normalised WITHOUT a zero guard (no such points -> NaN, as the reference).
+inline std::vector<float> gen_back_descriptors(const Cloud &back) {
+    static const int order_vec[26] = {0, 22, 0, 0, 21, 20, 0, 0, 0, 10, 11, 12, 13, 15, 16, 14, 17, 9, 18, 19, 0, 0, 0, 0, 0, 0};
+    const double max_dis = 50, min_dis = 5;
+    const int rings = 24, sectors = 360;
+    const double ring_step = (max_dis - min_dis) / rings, sector_step = 360. / sectors;
+    std::vector<char> build((size_t)rings * sectors, 0), road((size_t)rings * sectors, 0);
+    for (size_t i = 0; i < back.p.size(); ++i) {
+        const int label = back.l[i];
+        if (label < 0 || label > 25 || !(order_vec[label] > 0)) continue;
+        const Vec3 &p = back.p[i];
+        const double distance = std::sqrt(p.x * p.x + p.y * p.y);
+        if (distance >= max_dis || distance < min_dis) continue;
+        const int sector_id = int(fast_atan2_deg(p.y, p.x) / sector_step);
+        const int ring_id = int((distance - min_dis) / ring_step);
+        if (ring_id >= rings || ring_id < 0) continue;
+        if (sector_id >= sectors || sector_id < 0) continue;
+        if (label == 13) build[(size_t)ring_id * sectors + sector_id] = 1;
+        else if (label == 9) road[(size_t)ring_id * sectors + sector_id] = 1;
+    }
+    std::vector<float> d;
+    for (const auto *m : {&build, &road})
+        for (int r = 0; r < rings; ++r) {
+            float sum = 0.f;  // 0/1 entries: exact in any order
+            for (int c = 0; c < sectors; ++c) sum += (float)(*m)[(size_t)r * sectors + c];
+            d.push_back(sum);
+        }
+    const float ss = float_dot_self(d);
+    const float nrm = std::sqrt(ss);
+    for (float &x : d) x /= nrm;
+    return d;
+}
+// GenScanDescriptors (LoopClosure.cpp:15-32).  `cluster_cloud` is the 0.2 m cloud ClusterPoints was given: its
+// background part (labels 14, 15, 9, 13; SemanticCluster.cpp:234-242) is graph.back_points (SemGraphSLAM.cpp:50).
+inline std::vector<float> gen_scan_descriptors(const std::vector<Bbox> &boxes, const Cloud &cluster_cloud, double edge_dis_th,
+                                               int subinterval) {
+    Graph g;
+    for (size_t i = 0; i < boxes.size(); ++i) {
+        g.node_labels.push_back(boxes[i].label);
+        if (boxes[i].label == 1) g.vehicle_num++;
+        else if (boxes[i].label == 2) g.trunk_num++;
+        else if (boxes[i].label == 3) g.pole_like_num++;
+        for (size_t j = i + 1; j < boxes.size(); ++j) {
+            const double edge = norm(boxes[i].center - boxes[j].center);
+            if (edge < edge_dis_th) {
+                g.edges.emplace_back((int)i, (int)j);
+                g.edge_value.push_back(edge);
+            }
+        }
+    }
+    Cloud back;
+    for (size_t i = 0; i < cluster_cloud.p.size(); ++i) {
+        const int l = cluster_cloud.l[i];
+        if (l == 14 || l == 15 || l == 9 || l == 13) { back.p.push_back(cluster_cloud.p[i]); back.l.push_back(l); }
+    }
+    std::vector<float> d = gen_graph_descriptors(g, edge_dis_th, subinterval);
+    const std::vector<float> b = gen_back_descriptors(back);
+    d.insert(d.end(), b.begin(), b.end());
+    const float ss = float_dot_self(d);
+    float nrm = std::sqrt(ss);
+    if (nrm == 0) nrm = 0.000001f;
+    for (float &x : d) x /= nrm;
+    return d;
 }
 
 // ---- pipeline/SemGraphSLAM.{hpp,cpp} ----------------------------------------------------------

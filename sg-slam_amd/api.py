@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sgs_reset_stats", "sgs_set_profiling", "sgs_preprocess", "sgs_correct_kitti", "sgs_deskew",
     "sgs_voxel_keys", "sgs_voxel_downsample", "sgs_map_clear", "sgs_map_empty", "sgs_map_add_points",
     "sgs_map_update", "sgs_map_prune", "sgs_map_size", "sgs_map_pointcloud", "sgs_map_dump",
-    "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_shard_set", "sgs_fast_icp", "sgs_cluster_points",
+    "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_shard_set", "sgs_fast_icp", "sgs_scan_descriptor", "sgs_gen_scan_descriptor", "sgs_cluster_points",
     "sgs_build_graph", "sgs_process_scan", "sgs_process_scan_f32", "sgs_process_scan_f32_dev", "sgs_prefetch_scan_f32_dev", "sgs_get_cloud",
     "sgs_get_boxes", "sgs_get_poses", "sgs_remap_labels",
 ]
@@ -116,6 +116,8 @@ def lib():
         L.sgs_map_get_correspondences.argtypes = [c_vp, c_vp, c_int, c_dbl, c_vp, c_vp, c_vp, c_int, c_vp]
         L.sgs_build_linear_system.argtypes = [c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]
         L.sgs_register_frame.argtypes = [c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, c_vp, c_vp]
+        L.sgs_scan_descriptor.argtypes = [c_vp, c_vp, c_int, c_vp]
+        L.sgs_gen_scan_descriptor.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_dbl, c_int, c_vp, c_int, c_vp]
         L.sgs_fast_icp.argtypes = [c_vp, c_vp, c_int, c_vp, c_int, c_vp, ctypes.c_float, c_int, c_dbl, c_vp, c_vp]
         L.sgs_shard_set.argtypes = [c_vp, c_int, c_int, c_int, ALLREDUCE_FN, c_vp]
         L.sgs_cluster_points.argtypes = [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
@@ -299,6 +301,22 @@ class Context:
         self._ck(lib().sgs_register_frame(self.h, p.ctypes.data, len(p), g.ctypes.data, float(max_correspondence_distance),
                                           float(kernel), out.ctypes.data, ctypes.byref(it)))
         return out, it.value
+
+    # ---- GenScanDescriptors (loopclosure/LoopClosure.cpp:15-32) ----
+    def GenScanDescriptors(self, boxes, xyz, label, edge_dis_th=60.0, subinterval=30):
+        boxes = _f64(boxes).reshape(-1, 8); xyz = _f64(xyz); lab = _i32(label)
+        D = 6 * subinterval + 3 + 48
+        out = np.empty(D, dtype=np.float32); n = c_int()
+        self._ck(lib().sgs_gen_scan_descriptor(self.h, boxes.ctypes.data, len(boxes), xyz.ctypes.data, lab.ctypes.data, len(xyz),
+                                               float(edge_dis_th), int(subinterval), out.ctypes.data, D, ctypes.byref(n)))
+        return out[:n.value]
+
+    def scan_descriptor(self):
+        """Descriptor of the scan processed last (boxes + cluster cloud still on the device)."""
+        D = 6 * self.cfg.subinterval + 3 + 48
+        out = np.empty(D, dtype=np.float32); n = c_int()
+        self._ck(lib().sgs_scan_descriptor(self.h, out.ctypes.data, D, ctypes.byref(n)))
+        return out[:n.value]
 
     # ---- FastIcp::get_trans (loopclosure/FastIcp.cpp:205-220) ----
     def FastIcpGetTrans(self, xyzl_a, xyzl_b, init_pose7, voxel_size_map=1.0, max_points_per_voxel=5, max_corr=0.5):

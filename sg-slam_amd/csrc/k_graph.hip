@@ -792,6 +792,56 @@ void graph_scratch_free(GraphScratch &g) {
     g = GraphScratch();
 }
 
+// ---- background occupancy of the scan descriptor (loopclosure/LoopClosure.cpp:145-188 GenBackDescriptors) ----
+// 24 rings x 360 sectors over 5..50 m, one bit per cell, one bitmap for building (13) and one for road (9)
+// points: bitmap[which][ring][12 words].  fastAtan2 (LoopClosure.cpp:438-457) is evaluated in the same fp64
+// operation order as on the host, so a point lands in the cell the reference puts it in.
+namespace {
+__device__ inline double fast_atan2_deg(double y, double x) {
+    const double k = (double)(180 / 3.1415926535897932384626433832795);
+    const double p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k, p5 = 0.1555786518463281f * k,
+                 p7 = -0.04432655554792128f * k;
+    const double ax = fabs(x), ay = fabs(y);
+    double a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.0 - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.0 - a;
+    if (y < 0) a = 360.0 - a;
+    return a;
+}
+__global__ __launch_bounds__(256) void back_occupancy_kernel(CloudView in, const int32_t *__restrict__ n_ptr,
+                                                             uint32_t *__restrict__ bitmap) {
+    const int n = *n_ptr;
+    const double ring_step = (50.0 - 5.0) / 24, sector_step = 360. / 360;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int label = in.l[i];
+        if (label != 13 && label != 9) continue;
+        const double x = in.x[i], y = in.y[i];
+        const double distance = sqrt(x * x + y * y);
+        if (distance >= 50.0 || distance < 5.0) continue;
+        const int sector_id = int(fast_atan2_deg(y, x) / sector_step);
+        const int ring_id = int((distance - 5.0) / ring_step);
+        if (ring_id >= 24 || ring_id < 0 || sector_id >= 360 || sector_id < 0) continue;
+        atomicOr(&bitmap[((label == 13 ? 0 : 1) * 24 + ring_id) * kBackWordsPerRing + (sector_id >> 5)], 1u << (sector_id & 31));
+    }
+}
+}  // namespace
+
+void launch_back_occupancy(hipStream_t s, CloudView in, const int32_t *n_ptr, int n_upper, uint32_t *bitmap) {
+    hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * kBackBitmapWords, s);
+    if (n_upper <= 0) return;
+    int nb = (n_upper + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(back_occupancy_kernel, dim3(nb), dim3(256), 0, s, in, n_ptr, bitmap);
+}
+
 namespace {
 int graph_params_check(double edge_dis_th, int subinterval, int dim, int *sub_interval_value, std::string *err) {
     if (subinterval < 1 || 3 * subinterval > kMaxHistCols || dim < 0) return gfail(err, SGS_EINVAL, "bad graph parameters");

@@ -167,6 +167,7 @@ struct sgs_ctx {
     // state
     DevState *st = nullptr;
     DevState *st_host = nullptr;  // pinned
+    uint32_t *back_bitmap = nullptr;  // scan descriptor: occupancy bitmaps (kBackBitmapWords), allocated at first use
     // second map + state of the loop-pair refinement (sgs_fast_icp), allocated at its first call
     MapBuf loop_map;
     DevState *st_loop = nullptr;
@@ -1284,6 +1285,99 @@ int sgs_register_frame(sgs_ctx *c, const double *xyzl, int n, const double *gues
     rigid_to_pose7(c->st_host->T_total, out_pose7);
     if (iterations) *iterations = iters;
     return SGS_OK;
+}
+
+// ---- scan descriptor for the back-end: loopclosure/LoopClosure.cpp:15-32 GenScanDescriptors ----
+// graph part (:93-140) on the host from the boxes (<= 10^2 nodes), background part (:145-188) from the occupancy
+// bitmaps the device fills from the 0.2 m cluster cloud.  All normalisations in float with a float accumulator,
+// in the reference's order; the background part has no zero guard there (no building / road point -> NaN).
+namespace {
+float float_dot_self(const std::vector<float> &v) {
+    float acc = 0.0f;
+    for (float x : v) acc = acc + x * x;
+    return acc;
+}
+int scan_descriptor_from(sgs_ctx *c, const double *boxes, int nb, CloudView cloud, const int32_t *n_ptr, int n_upper,
+                         double edge_dis_th, int subinterval, float *desc, int cap, int *n_out) {
+    if (subinterval < 1 || !(edge_dis_th > 0)) return fail(c, SGS_EINVAL, "bad graph parameters");
+    const int D = 6 * subinterval + 3 + 48;
+    if (n_out) *n_out = D;
+    if (!desc || cap < D) return fail(c, SGS_ECAPACITY, "output capacity %d < %d", cap, D);
+    int r;
+    if (!c->back_bitmap && (r = dev_alloc(c, &c->back_bitmap, (size_t)kBackBitmapWords))) return r;
+    launch_back_occupancy(c->stream, cloud, n_ptr, n_upper, c->back_bitmap);
+    uint32_t bits[kBackBitmapWords];
+    SGS_HIP(c, hipMemcpyAsync(bits, c->back_bitmap, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    // graph part while the kernel runs
+    const float siv = float(edge_dis_th / subinterval);
+    std::vector<float> d((size_t)subinterval * 6 + 3, 0.f);
+    int cnt[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nb; ++i) {
+        const int a = (int)boxes[8 * (size_t)i + 6];
+        if (a >= 1 && a <= 3) cnt[a]++;
+        const D3 ci{boxes[8 * (size_t)i], boxes[8 * (size_t)i + 1], boxes[8 * (size_t)i + 2]};
+        for (int j = i + 1; j < nb; ++j) {
+            const D3 cj{boxes[8 * (size_t)j], boxes[8 * (size_t)j + 1], boxes[8 * (size_t)j + 2]};
+            const double edge = std::sqrt(sq3(sub(ci, cj)));
+            if (!(edge < edge_dis_th)) continue;
+            const int b = (int)boxes[8 * (size_t)j + 6];
+            int blk = -1;
+            if (a == b && a >= 1 && a <= 3) blk = a - 1;
+            else if ((a == 3 && b == 2) || (a == 2 && b == 3)) blk = 3;
+            else if ((a == 1 && b == 2) || (a == 2 && b == 1)) blk = 4;
+            else if ((a == 1 && b == 3) || (a == 3 && b == 1)) blk = 5;
+            if (blk >= 0) d[(size_t)(subinterval * blk + int(edge / siv) + 3)]++;
+        }
+    }
+    const double ss_edge = float_dot_self(d);
+    float n_edge = float(std::sqrt(ss_edge));
+    if (n_edge == 0) n_edge = 0.000001f;
+    for (float &x : d) x /= n_edge;
+    float n_cnt = float(std::sqrt(cnt[1] * cnt[1] + cnt[2] * cnt[2] + cnt[3] * cnt[3]));
+    if (n_cnt == 0) n_cnt = 0.000001f;
+    d[0] = ((float)cnt[1]) / n_cnt;
+    d[1] = ((float)cnt[2]) / n_cnt;
+    d[2] = ((float)cnt[3]) / n_cnt;
+    const float ss_all = float_dot_self(d);
+    float n_all = float(std::sqrt(ss_all));
+    if (n_all == 0) n_all = 0.000001f;
+    for (float &x : d) x /= n_all;
+    // background part
+    SGS_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<float> back(48);
+    for (int row = 0; row < 48; ++row) {
+        int pop = 0;
+        for (int w = 0; w < kBackWordsPerRing; ++w) pop += __builtin_popcount(bits[row * kBackWordsPerRing + w]);
+        back[(size_t)row] = (float)pop;
+    }
+    const float nb2 = std::sqrt(float_dot_self(back));
+    for (float &x : back) x /= nb2;
+    d.insert(d.end(), back.begin(), back.end());
+    float nrm = std::sqrt(float_dot_self(d));
+    if (nrm == 0) nrm = 0.000001f;
+    for (float &x : d) x /= nrm;
+    memcpy(desc, d.data(), sizeof(float) * (size_t)D);
+    return SGS_OK;
+}
+}  // namespace
+
+int sgs_gen_scan_descriptor(sgs_ctx *c, const double *boxes, int nb, const double *xyz, const int32_t *label, int n,
+                            double edge_dis_th, int subinterval, float *desc, int cap, int *n_out) {
+    ENTER(c);
+    CHECK_N(c, n);
+    if (nb < 0 || (nb && !boxes) || (n && (!xyz || !label))) return fail(c, SGS_EINVAL, "null argument");
+    int r;
+    if ((r = upload_xyz(c, xyz, n, c->aux, label))) return r;  // aux_n[0] = n
+    return scan_descriptor_from(c, boxes, nb, c->aux, &c->aux_n[0], n, edge_dis_th, subinterval, desc, cap, n_out);
+}
+
+int sgs_scan_descriptor(sgs_ctx *c, float *desc, int cap, int *n_out) {
+    ENTER(c);
+    if (!c->cfg.enable_graph) return fail(c, SGS_EINVAL, "the context was created with enable_graph = 0");
+    if (c->poses.empty()) return fail(c, SGS_EINVAL, "no scan has been processed yet");
+    ScanSet &S = c->S();
+    return scan_descriptor_from(c, S.boxes.data(), (int)(S.boxes.size() / 8), S.cluster, S.sizes + 1, c->last_n[2], c->cfg.edge_dis_th,
+                                c->cfg.subinterval, desc, cap, n_out);
 }
 
 // ---- loop-pair refinement: loopclosure/FastIcp.cpp:205-220 get_trans ----

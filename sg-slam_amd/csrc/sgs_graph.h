@@ -69,6 +69,11 @@ constexpr int kMaxNodes = 1024;       // graph nodes (boxes) per scan
 constexpr int kMaxClusters = 16384;   // non-empty instance clusters per scan (incl. those too small to become boxes)
 constexpr int kMaxHistCols = 3 * 256;
 
+// scan descriptor: ring x sector occupancy bitmaps, [2 (building, road)][24 rings][12 words of 32 sectors]
+constexpr int kBackWordsPerRing = 12;
+constexpr int kBackBitmapWords = 2 * 24 * kBackWordsPerRing;
+void launch_back_occupancy(hipStream_t s, CloudView in, const int32_t *n_ptr, int n_upper, uint32_t *bitmap /*device*/);
+
 int graph_scratch_alloc(GraphScratch &g, int N);
 void graph_scratch_free(GraphScratch &g);
 

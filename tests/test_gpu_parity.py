@@ -728,3 +728,47 @@ def test_fast_icp_leaves_the_odometry_pipeline_alone():
         rb = b.mainProcess(xyz, lab)
         assert np.array_equal(ra["pose"], rb["pose"]) and ra["map_voxels"] == rb["map_voxels"]
     a.close(); b.close()
+
+
+# ---------------- GenScanDescriptors, the back-end's scan descriptor ----------------
+@pytest.mark.parametrize("shape,frame", [("small", 4), ("hdl64", 12), ("os1_64", 7)])
+def test_scan_descriptor_matches_oracle(ctx_small, shape, frame):
+    _, xyz, lab = _scan(frame, shape)
+    px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
+    cx, cl, _, _ = O.voxel_downsample(px, pl, 0.2)
+    boxes, _, _, _ = O.cluster_points(cx, cl, 2.0, 0.5, 2.0)
+    want = O.scan_descriptor(boxes, cx, cl)
+    got = ctx_small.GenScanDescriptors(boxes, cx, cl)
+    assert got.shape == (231,) and np.array_equal(got, want)  # bit-exact: integer counts + the same float operations
+    assert abs(np.linalg.norm(got.astype(np.float64)) - 1) < 1e-6 and got[183:].any()
+    # other histogram parameters
+    assert np.array_equal(ctx_small.GenScanDescriptors(boxes, cx, cl, 40.0, 10), O.scan_descriptor(boxes, cx, cl, 40.0, 10))
+    # points on the axes, the diagonals and the ring limits: the cell decisions are the reference's
+    edge = np.array([[5.0, 0, 0], [0, 5.0, 0], [-5.0, 0, 0], [0, -5.0, 0], [49.999999, 0, 0], [50.0, 0, 0], [4.9999999, 0, 0],
+                     [10, 10, 0], [-10, 10, 0], [-10, -10, 0], [10, -10, 0], [6.875, 0, 1], [0, 6.874999999, 1],
+                     [20 * np.cos(np.radians(37.0)), 20 * np.sin(np.radians(37.0)), 0], [30 * np.cos(np.radians(359.5)), 30 * np.sin(np.radians(359.5)), 0]])
+    rng = np.random.default_rng(11)
+    t, r = np.radians(rng.integers(0, 360, 4000).astype(float)), rng.uniform(4, 51, 4000)  # whole-degree azimuths: sector borders
+    ring = np.stack([r * np.cos(t), r * np.sin(t), 0 * t], -1)
+    pts = np.concatenate([edge, ring])
+    labs = np.where(np.arange(len(pts)) % 3 == 0, 9, 13).astype(np.int32)
+    labs[1::7] = 15  # background, but neither building nor road
+    assert np.array_equal(ctx_small.GenScanDescriptors(boxes, pts, labs), O.scan_descriptor(boxes, pts, labs))
+    # no boxes: the graph part is zero; no building / road point: NaN like the reference (no zero guard)
+    assert np.array_equal(ctx_small.GenScanDescriptors(np.zeros((0, 8)), cx, cl), O.scan_descriptor(np.zeros((0, 8)), cx, cl))
+    veg = np.full(len(cl), 15, dtype=np.int32)
+    a, b = ctx_small.GenScanDescriptors(boxes, cx, veg), O.scan_descriptor(boxes, cx, veg)
+    assert np.isnan(a).all() and np.isnan(b).all()
+
+
+def test_scan_descriptor_of_the_last_processed_scan():
+    ctx = make_ctx()
+    slam = O.Slam(O.kitti_config())
+    for k in range(4):
+        _, xyz, lab = _scan(k, "hdl64")
+        ctx.mainProcess(xyz, lab)
+        slam.process(xyz, lab)
+        cx, cl = slam.cloud(1)
+        want = O.scan_descriptor(slam.boxes(), cx, cl)
+        assert np.array_equal(ctx.scan_descriptor(), want)
+    ctx.close()

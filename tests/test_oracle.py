@@ -419,3 +419,28 @@ def test_fast_icp_recovers_a_known_transform_and_uses_unit_weights():
     p_cap1, i1 = O.fast_icp(q, two, O.se3_exp([0] * 6), 1.0, 1, 2.0)
     p_cap5, i5 = O.fast_icp(q, two, O.se3_exp([0] * 6), 1.0, 5, 2.0)
     assert abs(p_cap5[4] + 0.02) < 1e-9 and abs(p_cap1[4] + 0.52) < 1e-9
+
+
+def test_scan_descriptor_known_answers():
+    """loopclosure/LoopClosure.cpp:15-188 restated: hand-checkable layout of the 231-D scan descriptor."""
+    import math
+    # fastAtan2 is a degree-valued polynomial approximation, accurate to ~0.01 deg, exact on the axes
+    assert O.fast_atan2(0, 1) == 0.0 and O.fast_atan2(1, 0) == 90.0 and O.fast_atan2(0, -1) == 180.0 and O.fast_atan2(-1, 0) == 270.0
+    for y, x in [(1, 1), (0.3, -2), (-5, 0.1), (-0.2, -0.9), (2, 7)]:
+        assert abs(O.fast_atan2(y, x) - math.degrees(math.atan2(y, x)) % 360) < 0.02
+    # two vehicles 3 m apart, a trunk 10 m from the first: bins = int(edge / 2.0)
+    boxes = np.array([[0, 0, 0, 1, 1, 1, 1, 50], [3, 0, 0, 1, 1, 1, 1, 50], [0, 10, 0, 1, 1, 1, 2, 30]], dtype=np.float64)
+    # background: building points in ring 0 at sectors 0 and 90, road point in ring 23
+    pts = np.array([[5.5, 0, 0], [5.6, 0.001, 0], [0, 6.0, 0], [49.0, 0, 0], [60.0, 0, 0], [3.0, 0, 0]])
+    lab = np.array([13, 13, 13, 9, 13, 9], dtype=np.int32)
+    d = O.scan_descriptor(boxes, pts, lab).astype(np.float64)
+    assert d.shape == (231,)
+    g, b = d[:183], d[183:]
+    nz = np.flatnonzero(g)
+    # counts (vehicle, trunk, pole) ; vehicle-vehicle bin 1 (3 m) ; vehicle-trunk bins 5 (10 m) and 5 (sqrt(109) = 10.44 m)
+    assert nz.tolist() == [0, 1, 3 + 1, 3 + 4 * 30 + 5]
+    assert g[3 + 4 * 30 + 5] / g[3 + 1] == pytest.approx(2.0, rel=1e-6) and g[0] / g[1] == pytest.approx(2.0, rel=1e-6)
+    assert np.flatnonzero(b).tolist() == [0, 24 + 23]          # building ring 0, road ring 23; 60 m and 3 m are out of range
+    assert b[0] / b[47] == pytest.approx(2.0, rel=1e-6)        # two occupied sectors against one (5.5 and 5.6 share sector 0)
+    assert np.linalg.norm(d) == pytest.approx(1.0, abs=1e-6)
+    assert np.linalg.norm(g) == pytest.approx(np.linalg.norm(b), rel=1e-6)  # both halves are unit vectors before the final scaling
