@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--sync-map-update", action="store_true",
                     help="wait for each scan's local-map update before the step returns (default: async_map_update=1, the "
                          "update overlaps the next step's preprocessing; all of it is inside the timed region either way)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="extra leg at N=1: this many independent scan streams (one context + one host thread each) on the ONE "
+                         "GPU, aggregate scans/s reported as `multi_stream` (SURVEY.md 8d); 0 = skip.  Never the headline value")
     args = ap.parse_args()
 
     import torch
@@ -170,6 +173,47 @@ def main():
         torch.cuda.synchronize()
         roofline["hbm_copy_gbs_measured"] = round(5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
         del a, b
+
+    if rank == 0 and world == 1 and args.streams > 1:
+        # several scan streams sharing one GPU: one stream leaves the GPU mostly idle (a latency-bound chain of
+        # small kernels), independent sequences fill it.  Every stream runs the same kind of pass as above
+        # (prefetch + async map update) over the same resident scans, in its own context and host thread.
+        import threading
+        S, Km = args.streams, min(K, 100)
+        cfg = api.preset("kitti", max_points=max(1 << 17, 1 << int(np.ceil(np.log2(n_pts)))), map_capacity_log2=args.map_log2,
+                         enable_graph=0 if args.no_graph else 1, async_map_update=0 if args.sync_map_update else 1)
+        ctxs = [api.Context(cfg, device=local_rank) for _ in range(S)]
+        last = np.zeros((S, 7))
+        bar = threading.Barrier(S + 1)
+
+        def drive(k):
+            ctx, res = ctxs[k], api.SgsScanResult()
+
+            def one(i):
+                if not args.no_prefetch and i + 1 < W + Km:
+                    ctx.prefetch_scan_dev(d_scans[i + 1].data_ptr(), d_labels[i + 1].data_ptr(), n_pts, "")
+                ctx.process_scan_dev(d_scans[i].data_ptr(), d_labels[i].data_ptr(), n_pts, None, "", res)
+            for i in range(W):
+                one(i)
+            bar.wait()
+            for i in range(W, W + Km):
+                one(i)
+            last[k] = res.pose[:]
+            bar.wait()
+
+        th = [threading.Thread(target=drive, args=(k,)) for k in range(S)]
+        [t.start() for t in th]
+        bar.wait()
+        t0 = time.perf_counter()
+        bar.wait()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        [t.join() for t in th]
+        fallbacks = sum(c.stats().icp_fallbacks for c in ctxs)
+        [c.close() for c in ctxs]
+        out["multi_stream"] = {"streams": S, "scans_per_stream": Km, "value": round(S * Km / el, 2), "unit": "scans/s",
+                               "per_stream": round(Km / el, 2), "icp_one_launch_fallbacks": int(fallbacks),
+                               "all_streams_same_pose_as_single": bool(all(np.array_equal(last[k], poses[W + Km - 1]) for k in range(S)))}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

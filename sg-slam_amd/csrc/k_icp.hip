@@ -550,6 +550,7 @@ constexpr uint32_t kSpinLimit = 1u << 21;
 __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, CloudView src, int src_cap,
                                                                      const int32_t *__restrict__ n_ptr, DevState *st,
                                                                      double *partials2 /*two [kIcpSums][kIcpBlocks] buffers*/,
+                                                                     uint32_t *tickets /*kIcpTickets counters, 128 B apart, zero*/,
                                                                      HostMirror *mirror) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -622,25 +623,32 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
                 __hip_atomic_store(&buf[(size_t)lane * gridDim.x + blockIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the arrival
-            if (lane == 0) {
-                __hip_atomic_fetch_add(&st->icp_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t target = (uint32_t)(it + 1) * gridDim.x;
-                int abort = 0;
-                for (uint32_t spins = 0;; ++spins) {
-                    const uint32_t t = __hip_atomic_load(&st->icp_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (t >= target) {
-                        abort = t >= kAbortBit ? 1 : 0;
-                        break;
-                    }
-                    if (spins > kSpinLimit) {
-                        __hip_atomic_fetch_add(&st->icp_ticket, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        abort = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
+            // arrival: the blocks are spread over kIcpTickets counters in different cache lines; lane l of the
+            // polling wave watches counter l.  (One counter for all blocks queues 256 read-modify-writes and
+            // every poll of the iteration on one memory channel: 215 us per launch against 160 us with 64
+            // counters; 16 -> 166 us, 32 -> 165 us; one plain-store flag word per block, 32 to a line -> 187 us;
+            // the sleep between polls makes no difference.)
+            if (lane == 0)
+                __hip_atomic_fetch_add(&tickets[(blockIdx.x % kIcpTickets) * kIcpTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t share = gridDim.x / kIcpTickets + ((uint32_t)lane < gridDim.x % kIcpTickets ? 1u : 0u);
+            const uint32_t target = (uint32_t)(it + 1) * share;
+            const bool watcher = lane < kIcpTickets;
+            int abort = 0;
+            for (uint32_t spins = 0;; ++spins) {
+                const uint32_t t = watcher ? __hip_atomic_load(&tickets[lane * kIcpTicketStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                if (__any(watcher && t >= kAbortBit)) {
+                    abort = 1;
+                    break;
                 }
-                s_flag = abort;
+                if (__all(!watcher || t >= target)) break;
+                if (spins > kSpinLimit) {
+                    if (watcher) __hip_atomic_fetch_add(&tickets[lane * kIcpTicketStride], kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    abort = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
+            if (lane == 0) s_flag = abort;
         }
         __syncthreads();
         if (s_flag) {
@@ -715,7 +723,10 @@ __global__ __launch_bounds__(256) void icp_finish_kernel(DevState *st, const dou
 }
 
 __global__ void icp_init_kernel(DevState *st, Rigid guess, double max_corr, double kernel_th, int max_iter,
-                                const int32_t *__restrict__ sizes4) {
+                                const int32_t *__restrict__ sizes4, uint32_t *tickets) {
+    if (tickets)
+        for (int k = threadIdx.x; k < kIcpTicketWords; k += blockDim.x) tickets[k] = 0;
+    if (threadIdx.x != 0) return;
     if (sizes4) { st->n_in = sizes4[0]; st->n_c = sizes4[1]; st->n_d = sizes4[2]; st->n_s = sizes4[3]; }
     st->guess = guess;
     st->T_icp = rigid_identity();
@@ -754,8 +765,8 @@ __global__ __launch_bounds__(256) void correspondences_kernel(MapView m, CloudVi
 }  // namespace
 
 void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max_corr, double kernel_th, int max_iter,
-                     const int32_t *sizes4) {
-    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, s, st, guess, max_corr, kernel_th, max_iter, sizes4);
+                     const int32_t *sizes4, uint32_t *tickets) {
+    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(64), 0, s, st, guess, max_corr, kernel_th, max_iter, sizes4, tickets);
 }
 
 void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
@@ -765,9 +776,9 @@ void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap, 
 }
 
 void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
-                           double *partials2, HostMirror *mirror) {
+                           double *partials2, uint32_t *tickets, HostMirror *mirror) {
     hipLaunchKernelGGL(icp_persistent_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st, partials2,
-                       mirror);
+                       tickets, mirror);
 }
 
 namespace {

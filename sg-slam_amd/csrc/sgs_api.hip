@@ -162,6 +162,7 @@ struct sgs_ctx {
     int4 *map_blockstat = nullptr;
     // icp
     double *partials = nullptr, *out28 = nullptr;
+    uint32_t *tickets = nullptr;  // arrival counters of the one-launch Gauss-Newton loop
     double *corr_tgt = nullptr;
     int32_t *corr_found = nullptr;
     // state
@@ -473,7 +474,7 @@ int run_icp_persistent(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *ite
         c->icp_events_used++;
         SGS_HIP(c, hipEventRecord(e0, c->stream));
     }
-    launch_icp_persistent(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, c->mirror_dev);
+    launch_icp_persistent(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, c->tickets, c->mirror_dev);
     if (e1) SGS_HIP(c, hipEventRecord(e1, c->stream));
     long spins = 0;
     int done;
@@ -542,7 +543,7 @@ int run_icp_sharded(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const Rigid
 
 int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const int32_t *sizes4, const Rigid &guess, double max_corr,
             double kernel_th, int *iters_out) {
-    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4);
+    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4, c->tickets);
     *iters_out = 0;
     if (c->shard_world > 1) return run_icp_sharded(c, src, n_ptr, guess, iters_out);
     if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
@@ -938,6 +939,7 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
         c->icp_persistent = !(e && e[0] == '1');
     }
     if ((r = dev_alloc(c, &c->out28, 32))) return bail(r);
+    if ((r = dev_alloc(c, &c->tickets, (size_t)kIcpTicketWords))) return bail(r);
     if ((r = dev_alloc(c, &c->corr_tgt, N * 4))) return bail(r);
     if ((r = dev_alloc(c, &c->corr_found, N))) return bail(r);
     if ((r = dev_alloc(c, &c->st, 1))) return bail(r);

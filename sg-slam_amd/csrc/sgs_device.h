@@ -62,6 +62,9 @@ struct MapView {
 constexpr int kIcpSums = 20;  // 16 moment sums + n_corr + candidates + probes + spare
 constexpr int kIcpBlocks = 256;     // x 4 waves = 1024 queries in flight, one wavefront each and at most one
 constexpr int kIcpThreads = 256;    // wavefront per SIMD: the per-query work is a serial instruction stream
+constexpr int kIcpTickets = 64;       // arrival counters of the one-launch loop's inter-block wait (<= 64: one per lane)
+constexpr int kIcpTicketStride = 32;  // uint32 words between two counters: one 128-B line each
+constexpr int kIcpTicketWords = kIcpTickets * kIcpTicketStride;
 
 struct DevState {
     // cloud sizes
@@ -127,7 +130,7 @@ void launch_map_clear(hipStream_t s, MapView m, DevState *st);
 // ---- k_icp.hip ----
 // sizes4 (nullable): device int32[4] {n_in, n_c, n_d, n_s} of the scan, copied into DevState
 void launch_icp_init(hipStream_t s, DevState *st, const Rigid &guess, double max_corr, double kernel_th,
-                     int max_iter, const int32_t *sizes4);
+                     int max_iter, const int32_t *sizes4, uint32_t *tickets = nullptr /*zeroed for launch_icp_persistent*/);
 // one Gauss-Newton iteration in ONE kernel: fused correspondence search + linear-system reduction;
 // with solve=true the last block to publish its partials folds them and runs the 6x6 solve + pose
 // update + convergence test (no second dispatch).  solve=false leaves the partials for
@@ -139,7 +142,7 @@ void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap /
 // or 2 when its inter-block wait ran out (then nothing was written and the caller repeats the loop with
 // launch_icp_iteration)
 void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
-                           double *partials2, HostMirror *mirror);
+                           double *partials2, uint32_t *tickets, HostMirror *mirror);
 void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const Rigid &T_total, int iter, long long corr);
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
                             int32_t *found);
