@@ -64,10 +64,12 @@ __device__ inline SearchConst search_const(const MapView &m) {
 // k < 0 and (-1, 1) * voxel for k == 0.  `reach` carries a millimetre of slack over the limit, far
 // above any fp32 rounding of the offsets.  When a nearest neighbour inside the limit exists its voxel
 // is always scanned, so results are unchanged; only the work is.
+// SHARD_CHECK = false: the caller knows the map is not sharded (saves the scalar registers of the test)
+template <bool SHARD_CHECK = true>
 __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &sc, D3 w, int lane, float reach) {
     const K3 kc{voxel_coord_fast(w.x, m.voxel, sc.inv_voxel), voxel_coord_fast(w.y, m.voxel, sc.inv_voxel),
                 voxel_coord_fast(w.z, m.voxel, sc.inv_voxel)};
-    if (m.shard_world > 1 && shard_owner(kc, m.shard_log2, m.shard_world) != m.shard_rank) {
+    if (SHARD_CHECK && m.shard_world > 1 && shard_owner(kc, m.shard_log2, m.shard_world) != m.shard_rank) {
         // sharded map: the rank that owns the centre voxel answers this query (it holds all 27 neighbours)
         QueryResult none;
         none.found = false; none.target = D3{0, 0, 0}; none.label = 0; none.candidates = 0; none.probes = 0;
@@ -434,6 +436,7 @@ __device__ inline void solve_and_update(DevState *st, const TailState &ts, const
 #pragma unroll
             for (int k = 0; k < 7; ++k) mirror->pose[k] = tq[k];
             mirror->icp_corr = corr; mirror->icp_cand = cand; mirror->icp_probe = probe;
+            mirror->icp_map_live = st->map_live; mirror->icp_map_tomb = st->map_tomb; mirror->icp_map_points = st->map_points;
         }
         __hip_atomic_store(&mirror->icp_iter, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&mirror->icp_done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -547,6 +550,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
 constexpr uint32_t kAbortBit = 1u << 30;
 constexpr uint32_t kSpinLimit = 1u << 21;
 
+template <bool SHARDED>
 __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, CloudView src, int src_cap,
                                                                      const int32_t *__restrict__ n_ptr, DevState *st,
                                                                      double *partials2 /*two [kIcpSums][kIcpBlocks] buffers*/,
@@ -560,19 +564,25 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     const D3 p0{src.x[qs], src.y[qs], src.z[qs]};  // the wave's first (usually only) query stays in registers
     const int label0 = src.l[qs];
     const int n = *n_ptr;
-    Rigid T_icp = st->T_icp, T_total = st->T_total;
+    if (mirror && blockIdx.x == 0 && threadIdx.x == 0) mirror->t_icp_start = wall_clock64();
+    Rigid T_total = st->T_total;
     const double max_corr = st->max_corr, th = st->kernel_th;
     const int max_iter = st->icp_max_iter;
     const SearchConst sc = search_const(m);
     const double max_corr2 = max_corr * max_corr, th2 = th * th;
     const bool plain = th < 0.0;  // no robust kernel, no class weight (loopclosure/FastIcp.cpp:146-152)
     const float reach = (float)max_corr + 1e-3f;
-    long long corr = 0, cand = 0, probe = 0;
     __shared__ double red[kIcpThreads / 64][kIcpSums];
     __shared__ double S[kIcpSums];
     __shared__ SolveLds solve_lds;
-    __shared__ Rigid s_T[2];
+    // state only thread 0 / the solving lanes need stays in LDS: the kernel is short of scalar registers
+    __shared__ Rigid s_T[2];         // [0] T_icp, [1] T_total
+    __shared__ long long s_cnt[3];   // correspondences, candidates, probes summed over the iterations
     __shared__ int s_flag;  // after the wait: 1 = abort; after the solve: 1 = converged
+    if (threadIdx.x == 0) {
+        s_T[0] = st->T_icp;
+        s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+    }
     int it = 0;
     bool done = false;
     while (it < max_iter) {
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
                 p = D3{src.x[q], src.y[q], src.z[q]};
                 label = src.l[q];
             }
-            const QueryResult r = wave_nearest(m, sc, s, lane, reach);
+            const QueryResult r = wave_nearest<SHARDED>(m, sc, s, lane, reach);
             acc[17] += (double)r.candidates;
             acc[18] += (double)r.probes;
             if (!r.found) continue;
@@ -652,6 +662,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
         }
         __syncthreads();
         if (s_flag) {
+            if (threadIdx.x == 0 && blockIdx.x == 0) st->icp_abort = 1;  // a map update queued behind this launch skips itself
             if (threadIdx.x == 0 && mirror) __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
@@ -674,23 +685,24 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
 #pragma unroll
                 for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
                 const Rigid est = rigid_exp_small(D3{x[0], x[1], x[2]}, D3{x[3], x[4], x[5]});
-                s_T[lane] = compose_fast(est, lane == 0 ? T_icp : T_total);  // [0] T_icp, [1] T_total
-                if (lane == 0) s_flag = (nn < 1e-8) ? 1 : 0;  // F/Registration.cpp:169
+                const Rigid prev = lane == 0 ? s_T[0] : T_total;
+                s_T[lane] = compose_fast(est, prev);
+                if (lane == 0) {
+                    s_flag = (nn < 1e-8) ? 1 : 0;  // F/Registration.cpp:169
+                    s_cnt[0] += (long long)S[16]; s_cnt[1] += (long long)S[17]; s_cnt[2] += (long long)S[18];
+                }
             }
         }
         __syncthreads();
-        T_icp = s_T[0];
         T_total = s_T[1];
-        corr += (long long)S[16];
-        cand += (long long)S[17];
-        probe += (long long)S[18];
         ++it;
         done = s_flag != 0;
         if (done) break;
         __syncthreads();  // S, s_T, s_flag and red are rewritten by the next iteration
     }
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    st->T_icp = T_icp;
+    const long long corr = s_cnt[0], cand = s_cnt[1], probe = s_cnt[2];
+    st->T_icp = s_T[0];
     st->T_total = T_total;
     st->icp_corr = corr; st->icp_cand = cand; st->icp_probe = probe;
     st->icp_iter = it;
@@ -701,6 +713,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
         mirror->pose[0] = T_total.qw; mirror->pose[1] = T_total.qx; mirror->pose[2] = T_total.qy; mirror->pose[3] = T_total.qz;
         mirror->pose[4] = T_total.t.x; mirror->pose[5] = T_total.t.y; mirror->pose[6] = T_total.t.z;
         mirror->icp_corr = corr; mirror->icp_cand = cand; mirror->icp_probe = probe;
+        mirror->icp_map_live = st->map_live; mirror->icp_map_tomb = st->map_tomb; mirror->icp_map_points = st->map_points;
+        mirror->t_icp_end = wall_clock64();
         __hip_atomic_store(&mirror->icp_iter, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&mirror->icp_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -737,6 +751,7 @@ __global__ void icp_init_kernel(DevState *st, Rigid guess, double max_corr, doub
     st->icp_done = 0;
     st->icp_max_iter = max_iter;
     st->icp_ticket = 0;
+    st->icp_abort = 0;
     st->icp_corr = 0;
     st->icp_cand = 0;
     st->icp_probe = 0;
@@ -777,8 +792,12 @@ void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap, 
 
 void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
                            double *partials2, uint32_t *tickets, HostMirror *mirror) {
-    hipLaunchKernelGGL(icp_persistent_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st, partials2,
-                       tickets, mirror);
+    if (m.shard_world > 1)
+        hipLaunchKernelGGL(icp_persistent_kernel<true>, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st,
+                           partials2, tickets, mirror);
+    else
+        hipLaunchKernelGGL(icp_persistent_kernel<false>, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st,
+                           partials2, tickets, mirror);
 }
 
 namespace {

@@ -40,6 +40,7 @@ __global__ void map_reset_counters_kernel(DevState *st) {
 __global__ __launch_bounds__(kBlock) void map_add_kernel(MapView m, CloudView in, const int32_t *__restrict__ n_ptr,
                                                          const Rigid *__restrict__ T_dev, int32_t *__restrict__ slot_of,
                                                          int32_t *__restrict__ next, CloudView world, DevState *st) {
+    if (m.skip && *m.skip) return;
     const int n = *n_ptr;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(kBlock) void map_append_kernel(MapView m, CloudView
                                                             const int32_t *__restrict__ slot_of,
                                                             const int32_t *__restrict__ next, CloudView world,
                                                             DevState *st) {
+    if (m.skip && *m.skip) return;
     const int n = *n_ptr;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void map_append_kernel(MapView m, CloudView
 // map_census_kernel folds the per-block numbers into DevState so no contended atomics are needed.
 __global__ __launch_bounds__(kBlock) void map_prune_kernel(MapView m, const Rigid *__restrict__ T_dev, D3 origin_host,
                                                            double max_d2, int do_prune, int4 *__restrict__ blockstat) {
+    if (m.skip && *m.skip) return;
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
     int live = 0, tomb = 0, pts = 0;
     if (s <= m.mask) {
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(kBlock) void map_prune_kernel(MapView m, const Rigi
 }
 
 __global__ __launch_bounds__(kBlock) void map_census_kernel(const int4 *__restrict__ blockstat, int nblocks, DevState *st,
-                                                            HostMirror *mirror) {
+                                                            HostMirror *mirror, const int32_t *__restrict__ skip) {
+    if (skip && *skip) return;
     int live = 0, tomb = 0, pts = 0;
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
         const int4 v = blockstat[b];
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void map_census_kernel(const int4 *__restri
             mirror->map_tomb = t;
             mirror->map_points = p;
             mirror->map_err_flags = st->err_flags;
+            mirror->t_census_end = wall_clock64();
             __hip_atomic_store(&mirror->census_seq, mirror->census_seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -241,7 +246,7 @@ void launch_map_sweep(hipStream_t s, MapView m, const Rigid *T_dev, const double
     const int nb = (int)((cap + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(map_prune_kernel, dim3(nb), dim3(kBlock), 0, s, m, T_dev, o, max_dist * max_dist, do_prune,
                        blockstat);
-    hipLaunchKernelGGL(map_census_kernel, dim3(1), dim3(kBlock), 0, s, blockstat, nb, st, mirror);
+    hipLaunchKernelGGL(map_census_kernel, dim3(1), dim3(kBlock), 0, s, blockstat, nb, st, mirror, m.skip);
 }
 
 void launch_map_rehash(hipStream_t s, MapView from, MapView to, DevState *st) {

@@ -138,6 +138,19 @@ struct sgs_ctx {
     HostMirror *mirror = nullptr;    // host-pinned, device-mapped: ICP progress, pose / sizes of the scan, map census
     HostMirror *mirror_dev = nullptr;
     bool async_pending = false;      // a map update of sgs_process_scan is still queued (cfg.async_map_update)
+    // Chained registration: when scan k+1 has been prefetched, the call for scan k ends by enqueueing the
+    // registration of scan k+1 (its guess and threshold depend only on the poses up to k), so the device goes
+    // from the map update of k straight into the Gauss-Newton loop of k+1 without waiting for the host.
+    bool next_params_valid = false;  // next_guess / next_sigma hold for whatever scan comes next
+    Rigid next_guess = rigid_identity();
+    double next_sigma = 0.0;
+    int chained_set = -1;            // ScanSet whose registration is already enqueued, or -1
+    // SGS_TRACE=1: device-side timeline of the registration stream, printed at sgs_destroy
+    bool trace = false;
+    unsigned long long tr_prev_icp_end = 0;
+    double tr_icp = 0, tr_icp_to_census = 0, tr_census_to_icp = 0, tr_cycle = 0;
+    long tr_n = 0, tr_chained = 0;
+    double tr_host_done_to_chain = 0;
     std::string err;
     std::vector<void *> allocs;
     int N = 0;  // max points per scan
@@ -162,7 +175,7 @@ struct sgs_ctx {
     int4 *map_blockstat = nullptr;
     // icp
     double *partials = nullptr, *out28 = nullptr;
-    uint32_t *tickets = nullptr;  // arrival counters of the one-launch Gauss-Newton loop
+    uint32_t *tickets = nullptr;  // arrival counters of the one-launch Gauss-Newton loop (zeroed by icp_init)
     double *corr_tgt = nullptr;
     int32_t *corr_found = nullptr;
     // state
@@ -376,6 +389,17 @@ DsJob make_job(sgs_ctx *c, int which, CloudView in, const int32_t *n_in, double 
 bool bad_ctx(sgs_ctx *c) { return c == nullptr; }
 
 // P/SemGraphSLAM.cpp:147-159 + F/Threshold.cpp:29-50
+double adaptive_threshold(sgs_ctx *c);
+// initial guess and threshold of the NEXT scan from the pose history (P/SemGraphSLAM.cpp:57-63); call once per scan
+void next_scan_params(sgs_ctx *c, Rigid *guess, double *sigma) {
+    *sigma = adaptive_threshold(c);
+    Rigid prediction = rigid_identity();
+    const size_t NP = c->poses.size();
+    if (NP >= 2) prediction = compose(invert(c->poses[NP - 2]), c->poses[NP - 1]);
+    const Rigid last_pose = NP ? c->poses.back() : rigid_identity();
+    *guess = compose(last_pose, prediction);
+}
+
 double adaptive_threshold(sgs_ctx *c) {
     bool moved = false;
     if (!c->poses.empty()) {
@@ -454,13 +478,12 @@ int run_icp_per_launch(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *ite
     return SGS_OK;
 }
 
-// the whole loop in one launch; *fell_back = true when its inter-block wait ran out and nothing was done
-int run_icp_persistent(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *iters_out, bool *fell_back) {
+// the whole loop in one launch: enqueue ...
+int icp_persistent_launch(sgs_ctx *c, CloudView src, const int32_t *n_ptr) {
     volatile int32_t *mb = &c->mirror->icp_iter;
     mb[0] = 0;
     mb[1] = 0;
     __sync_synchronize();
-    *fell_back = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) {
         if (c->icp_events_used == c->icp_events.size()) {
@@ -476,6 +499,12 @@ int run_icp_persistent(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *ite
     }
     launch_icp_persistent(c->stream, c->map.v, src, c->N, n_ptr, c->st, c->partials, c->tickets, c->mirror_dev);
     if (e1) SGS_HIP(c, hipEventRecord(e1, c->stream));
+    return SGS_OK;
+}
+// ... and wait for it; *fell_back = true when its inter-block wait ran out and nothing was done
+int icp_persistent_wait(sgs_ctx *c, int *iters_out, bool *fell_back) {
+    volatile int32_t *mb = &c->mirror->icp_iter;
+    *fell_back = false;
     long spins = 0;
     int done;
     while (!(done = __atomic_load_n(&mb[1], __ATOMIC_ACQUIRE))) {
@@ -500,6 +529,10 @@ int run_icp_persistent(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *ite
     }
     *iters_out = __atomic_load_n(&mb[0], __ATOMIC_ACQUIRE);
     return SGS_OK;
+}
+int run_icp_persistent(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *iters_out, bool *fell_back) {
+    const int r = icp_persistent_launch(c, src, n_ptr);
+    return r ? r : icp_persistent_wait(c, iters_out, fell_back);
 }
 
 // Gauss-Newton loop against a map that is sharded by key over ranks (sgs_shard_set): every rank holds the
@@ -542,16 +575,20 @@ int run_icp_sharded(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const Rigid
 }
 
 int run_icp(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const int32_t *sizes4, const Rigid &guess, double max_corr,
-            double kernel_th, int *iters_out) {
-    launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4, c->tickets);
-    *iters_out = 0;
-    if (c->shard_world > 1) return run_icp_sharded(c, src, n_ptr, guess, iters_out);
-    if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
+            double kernel_th, int *iters_out, bool launched = false) {
     int iters = 0, r;
     bool fell_back = !c->icp_persistent;
-    if (c->icp_persistent && (r = run_icp_persistent(c, src, n_ptr, &iters, &fell_back))) return r;
+    *iters_out = 0;
+    if (launched) {  // icp_init + the one-launch loop were enqueued at the end of the previous scan's call
+        if ((r = icp_persistent_wait(c, &iters, &fell_back))) return r;
+    } else {
+        launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4, c->tickets);
+        if (c->shard_world > 1) return run_icp_sharded(c, src, n_ptr, guess, iters_out);
+        if (c->map_live_host == 0) return SGS_OK;  // F/Registration.cpp:152: empty map -> initial guess
+        if (c->icp_persistent && (r = run_icp_persistent(c, src, n_ptr, &iters, &fell_back))) return r;
+    }
     if (fell_back) {
-        if (c->icp_persistent) launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4);
+        if (c->icp_persistent) launch_icp_init(c->stream, c->st, guess, max_corr, kernel_th, kIcpMaxIter, sizes4, c->tickets);
         if ((r = run_icp_per_launch(c, src, n_ptr, &iters))) return r;
     }
     *iters_out = iters;
@@ -664,7 +701,19 @@ void discard_prefetch(sgs_ctx *c, ScanSet &N) {
     hipStreamSynchronize(c->stream2);
     N.prefetched = false;
 }
+// a registration enqueued ahead for a scan that is not the one asked for now: let it finish, ignore its result
+// (it only wrote the registration state, which every registration initialises for itself)
+int cancel_chained_icp(sgs_ctx *c) {
+    if (c->chained_set < 0) return SGS_OK;
+    c->chained_set = -1;
+    int iters = 0;
+    bool fell_back = false;
+    const int r = icp_persistent_wait(c, &iters, &fell_back);
+    if (c->profiling && c->icp_events_used) c->icp_events_used--;
+    return r;
+}
 void discard_prefetch(sgs_ctx *c) {
+    cancel_chained_icp(c);
     discard_prefetch(c, c->sets[0]);
     discard_prefetch(c, c->sets[1]);
 }
@@ -714,61 +763,95 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
         ScanSet *s;
         ~JobGuard() { wait_set_job(*s); }
     } guard{&S};
-    SGS_HIP(c, hipStreamWaitEvent(s, S.ev_front, 0));
+    // a registration chained to the previous call is this scan's only if it was enqueued for this set
+    const bool chained = c->chained_set == c->cur;
+    if (!chained) {
+        int rc = cancel_chained_icp(c);
+        if (rc) return rc;
+        SGS_HIP(c, hipStreamWaitEvent(s, S.ev_front, 0));
+    }
+    c->chained_set = -1;
     // ---- motion prediction and threshold (P/SemGraphSLAM.cpp:57-63)
-    const double sigma = adaptive_threshold(c);
-    Rigid prediction = rigid_identity();
-    const size_t NP = c->poses.size();
-    if (NP >= 2) prediction = compose(invert(c->poses[NP - 2]), c->poses[NP - 1]);
-    const Rigid last_pose = NP ? c->poses.back() : rigid_identity();
-    const Rigid guess = compose(last_pose, prediction);
-    // ---- registration (P/SemGraphSLAM.cpp:72-76)
-    int iters = 0;
+    double sigma;
+    Rigid guess;
+    if (c->next_params_valid) {  // worked out at the end of the previous call (they depend on the poses only)
+        sigma = c->next_sigma;
+        guess = c->next_guess;
+        c->next_params_valid = false;
+    } else {
+        next_scan_params(c, &guess, &sigma);
+    }
+    // ---- registration (P/SemGraphSLAM.cpp:72-76) and local map update with the new pose (P/SemGraphSLAM.cpp:113),
+    // both on the device.  cfg.async_map_update: everything the caller gets back is left in the host mirror by the
+    // kernel that ends the Gauss-Newton loop, so the call returns while the update still runs (same stream: the
+    // next registration sees the updated map).  With the one-launch loop the update is enqueued BEFORE the loop
+    // has finished - the device goes from one into the other without waiting for the host; should the loop give
+    // up (its inter-block wait ran out) the queued update skips itself and both are repeated the slow way.
+    int iters = 0, r;
     const double t_icp0 = now_ms();
-    int r = run_icp(c, S.src, S.sizes + 3, S.sizes, guess, 3.0 * sigma, sigma / 3.0, &iters);
-    c->stats.stage_ms[7] += now_ms() - t_icp0;  // host wall time of the ICP loop
-    if (r) return r;
-    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[3], s);
-    // ---- local map update with the new pose, still on the device (P/SemGraphSLAM.cpp:113)
-    // cfg.async_map_update: the update is only ENQUEUED here; everything the caller gets back was left
-    // in the host mirror by the kernel that ended the ICP loop, so the call returns while the update
-    // runs and the next scan's preprocessing is queued behind it (same stream, so the next ICP sees the
-    // updated map).  Needs an ICP loop that ran (not the first scan of a sequence).
-    const bool async = cfg.async_map_update != 0 && iters > 0 && !c->profiling && c->shard_world == 1;
+    const bool ahead = cfg.async_map_update != 0 && !c->profiling && c->shard_world == 1 && c->icp_persistent && c->map_live_host != 0;
+    auto enqueue_map_update = [&](bool guarded) -> int {
+        // sizing by the last census the host has seen plus everything that may have been added since
+        int rr = maybe_rehash(c, guarded ? n + c->last_n[3] : n);
+        if (rr) return rr;
+        MapView mv = c->map.v;
+        mv.skip = guarded ? &c->st->icp_abort : nullptr;
+        launch_map_add(s, mv, S.ds, S.sizes + 2, n, &c->st->T_total, c->map_slot_of, c->map_next, c->world, c->st);
+        launch_map_sweep(s, mv, &c->st->T_total, nullptr, cfg.max_range, 1, c->map_blockstat, c->st, c->mirror_dev);
+        SGS_HIP(c, hipEventRecord(S.ev_free, s));
+        S.free_recorded = true;
+        return SGS_OK;
+    };
+    if (ahead) {
+        if (!chained) {
+            launch_icp_init(s, c->st, guess, 3.0 * sigma, sigma / 3.0, kIcpMaxIter, S.sizes, c->tickets);
+            if ((r = icp_persistent_launch(c, S.src, S.sizes + 3))) return r;
+        }
+        if ((r = enqueue_map_update(true))) return r;
+        const uint64_t fb0 = c->stats.icp_fallbacks;
+        r = run_icp(c, S.src, S.sizes + 3, S.sizes, guess, 3.0 * sigma, sigma / 3.0, &iters, true);
+        c->stats.stage_ms[7] += now_ms() - t_icp0;  // host wall time of the ICP loop
+        if (r) return r;
+        if (c->stats.icp_fallbacks != fb0 && (r = enqueue_map_update(false))) return r;  // the queued one skipped itself
+    } else {
+        r = run_icp(c, S.src, S.sizes + 3, S.sizes, guess, 3.0 * sigma, sigma / 3.0, &iters, chained);
+        c->stats.stage_ms[7] += now_ms() - t_icp0;
+        if (r) return r;
+        if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[3], s);
+    }
+    const double t_icp_done = now_ms();
+    const bool async = ahead || (cfg.async_map_update != 0 && iters > 0 && !c->profiling && c->shard_world == 1);
     DevState hs;  // host view of the device state for this scan
     if (async) {
         const HostMirror &mi = *c->mirror;
-        // the census of the previous update finished before this scan's ICP could start
-        c->map_live_host = mi.map_live; c->map_tomb_host = mi.map_tomb; c->map_points_host = mi.map_points;
+        if (c->trace) {  // 100 MHz device clock: this scan's kernel, and the gaps around the previous map update
+            if (c->tr_prev_icp_end && mi.t_census_end > c->tr_prev_icp_end && mi.t_icp_start > mi.t_census_end) {
+                c->tr_icp += (mi.t_icp_end - mi.t_icp_start) * 1e-5;
+                c->tr_icp_to_census += (mi.t_census_end - c->tr_prev_icp_end) * 1e-5;
+                c->tr_census_to_icp += (mi.t_icp_start - mi.t_census_end) * 1e-5;
+                c->tr_cycle += (mi.t_icp_end - c->tr_prev_icp_end) * 1e-5;
+                c->tr_n++;
+            }
+            c->tr_prev_icp_end = mi.t_icp_end;
+        }
+        // the census the registration kernel saw is that of the previous scan's update
+        c->map_live_host = mi.icp_map_live; c->map_tomb_host = mi.icp_map_tomb; c->map_points_host = mi.icp_map_points;
         hs.n_in = mi.n_in; hs.n_c = mi.n_c; hs.n_d = mi.n_d; hs.n_s = mi.n_s;
         hs.err_flags = mi.err_flags | mi.map_err_flags;
         hs.T_total = Rigid{mi.pose[0], mi.pose[1], mi.pose[2], mi.pose[3], D3{mi.pose[4], mi.pose[5], mi.pose[6]}};
         hs.icp_corr = mi.icp_corr; hs.icp_cand = mi.icp_cand; hs.icp_probe = mi.icp_probe;
-        hs.map_live = mi.map_live;  // voxels of the map this scan was registered against
+        hs.map_live = mi.icp_map_live;  // voxels of the map this scan was registered against
     }
-    r = maybe_rehash(c, n);
-    if (r) return r;
-    launch_map_add(s, c->map.v, S.ds, S.sizes + 2, n, &c->st->T_total, c->map_slot_of, c->map_next, c->world, c->st);
-    launch_map_sweep(s, c->map.v, &c->st->T_total, nullptr, cfg.max_range, 1, c->map_blockstat, c->st, c->mirror_dev);
-    SGS_HIP(c, hipEventRecord(S.ev_free, s));
-    S.free_recorded = true;
-    if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[4], s);
-    // ---- collect the clusters, emit boxes in the reference's order, build the graph (P/SemGraphSLAM.cpp:44-51)
-    int n_boxes = 0;
+    if (!ahead) {
+        if ((r = enqueue_map_update(false))) return r;
+        if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[4], s);
+    }
     if (async) {
         c->async_pending = true;
     } else {
         r = sync_state(c);
         if (r) return r;
         hs = *c->st_host;
-    }
-    if (cfg.enable_graph) {
-        wait_set_job(S);
-        if (S.graph_rc) {
-            c->err = S.gerr;
-            return S.graph_rc;
-        }
-        n_boxes = S.n_boxes;
     }
     r = check_err_flags(c, hs.err_flags);
     if (r) return r;
@@ -777,6 +860,30 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     // ---- model deviation / pose list (P/SemGraphSLAM.cpp:79,110,119)
     c->model_deviation = compose(invert(guess), new_pose);
     c->poses.push_back(new_pose);
+    // ---- chain the next scan's registration behind this scan's map update when its front half is already
+    // enqueued (sgs_prefetch_scan_f32_dev): the device never waits for the host between two scans
+    if (async && c->icp_persistent) {
+        ScanSet &Nx = c->sets[c->cur ^ 1];
+        if (Nx.prefetched && Nx.front_enqueued.load(std::memory_order_acquire) && Nx.front_rc == 0) {
+            next_scan_params(c, &c->next_guess, &c->next_sigma);
+            c->next_params_valid = true;
+            if (hipEventQuery(Nx.ev_front) != hipSuccess) SGS_HIP(c, hipStreamWaitEvent(s, Nx.ev_front, 0));  // usually long done
+            launch_icp_init(s, c->st, c->next_guess, 3.0 * c->next_sigma, c->next_sigma / 3.0, kIcpMaxIter, Nx.sizes, c->tickets);
+            if ((r = icp_persistent_launch(c, Nx.src, Nx.sizes + 3))) return r;
+            c->chained_set = c->cur ^ 1;
+            if (c->trace) { c->tr_chained++; c->tr_host_done_to_chain += now_ms() - t_icp_done; }
+        }
+    }
+    // ---- collect the clusters, emit boxes in the reference's order, build the graph (P/SemGraphSLAM.cpp:44-51)
+    int n_boxes = 0;
+    if (cfg.enable_graph) {
+        wait_set_job(S);
+        if (S.graph_rc) {
+            c->err = S.gerr;
+            return S.graph_rc;
+        }
+        n_boxes = S.n_boxes;
+    }
     c->last_n[0] = n; c->last_n[1] = h.n_in; c->last_n[2] = h.n_c; c->last_n[3] = h.n_d; c->last_n[4] = h.n_s;
     c->stats.scans++;
     c->stats.stage_ms[6] += now_ms() - t_call0;  // host wall time of the whole call
@@ -937,6 +1044,8 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     {
         const char *e = getenv("SGS_ICP_PER_LAUNCH");
         c->icp_persistent = !(e && e[0] == '1');
+        const char *t = getenv("SGS_TRACE");
+        c->trace = t && t[0] == '1';
     }
     if ((r = dev_alloc(c, &c->out28, 32))) return bail(r);
     if ((r = dev_alloc(c, &c->tickets, (size_t)kIcpTicketWords))) return bail(r);
@@ -961,6 +1070,10 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
 void sgs_destroy(sgs_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->trace && c->tr_n)
+        fprintf(stderr, "[sgs trace] %ld scans, device ms per scan: GN kernel %.4f | its end -> end of map update %.4f | -> next GN kernel start %.4f | cycle %.4f; %ld registrations chained, host ms from 'loop done' to 'next loop enqueued' %.4f\n",
+                c->tr_n, c->tr_icp / c->tr_n, c->tr_icp_to_census / c->tr_n, c->tr_census_to_icp / c->tr_n, c->tr_cycle / c->tr_n,
+                c->tr_chained, c->tr_chained ? c->tr_host_done_to_chain / c->tr_chained : 0.0);
     c->gworker.wait_idle();
     c->fworker.wait_idle();
     c->gworker.stop();

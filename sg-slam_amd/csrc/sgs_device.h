@@ -57,6 +57,9 @@ struct MapView {
     // key sharding over ranks (shard_world <= 1: off): inserts keep owned + halo voxels only, the
     // registration kernels skip queries whose centre voxel another rank owns
     int32_t shard_rank = 0, shard_world = 1, shard_log2 = 3;
+    // map update enqueued BEFORE the registration it depends on has finished: the map kernels do nothing
+    // when *skip != 0 (the one-launch Gauss-Newton loop gave up; the host repeats registration and update)
+    const int32_t *skip = nullptr;
 };
 
 constexpr int kIcpSums = 20;  // 16 moment sums + n_corr + candidates + probes + spare
@@ -78,7 +81,8 @@ struct DevState {
     uint32_t icp_ticket;  // blocks of the running accumulate kernel that have published their partials
     long long icp_corr, icp_cand, icp_probe;
     // map
-    int32_t map_live, map_tomb, map_points, pad1;
+    int32_t map_live, map_tomb, map_points;
+    int32_t icp_abort;  // set by the one-launch loop when its inter-block wait ran out, cleared by icp_init
     long long cas_retries;
 };
 
@@ -95,6 +99,10 @@ struct HostMirror {
     long long icp_corr, icp_cand, icp_probe;
     int32_t map_live, map_tomb, map_points, map_err_flags;  // written by every map sweep (census)
     int32_t census_seq, pad1;
+    int32_t icp_map_live, icp_map_tomb, icp_map_points, pad2;  // census of the map the registration ran against
+    // device timestamps (wall_clock64, 100 MHz) for SGS_TRACE=1: start / end of the one-launch Gauss-Newton
+    // kernel and end of the map update's census kernel
+    unsigned long long t_icp_start, t_icp_end, t_census_end;
 };
 
 // ---- k_pre.hip ----
@@ -123,7 +131,7 @@ void launch_map_add(hipStream_t s, MapView m, CloudView in, const int32_t *n_ptr
                     DevState *st);
 // sweep = optional prune (origin = T_dev->t when T_dev != nullptr, else origin3_host) + census into st
 void launch_map_sweep(hipStream_t s, MapView m, const Rigid *T_dev, const double *origin3_host, double max_dist,
-                      int do_prune, int4 *blockstat, DevState *st, HostMirror *mirror /*host-mapped, nullable*/);
+                      int do_prune, int4 *blockstat, DevState *st, HostMirror *mirror /*host-mapped, nullable*/);  // honours m.skip
 void launch_map_rehash(hipStream_t s, MapView from, MapView to, DevState *st);
 void launch_map_clear(hipStream_t s, MapView m, DevState *st);
 

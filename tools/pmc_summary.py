@@ -1,0 +1,37 @@
+"""Per-kernel means of a rocprofv3 --pmc pass (CSV output) -> JSON.
+
+  python tools/pmc_summary.py <counter_collection.csv> <out.json> "<command line the pass ran>"
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def main():
+    path, out, command = sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else ""
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"(\w+)\(", r["Kernel_Name"])
+        k = m.group(1) if m else r["Kernel_Name"]
+        a = agg[k][r["Counter_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    kernels = {}
+    for k, cs in sorted(agg.items()):
+        e = {c: round(v / n, 1) for c, (n, v) in sorted(cs.items())}
+        e["dispatches"] = max(n for n, _ in cs.values())
+        if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e and e["TCC_HIT_sum"] + e["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = round(e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"]), 4)
+        if "SQ_LDS_BANK_CONFLICT" in e and e.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
+            e["lds_bank_conflict_frac"] = round(e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"], 4)
+        if "SQ_INSTS_VALU" in e and e.get("SQ_WAVES", 0) > 0:
+            e["valu_insts_per_wave"] = round(e["SQ_INSTS_VALU"] / e["SQ_WAVES"], 1)
+        kernels[k] = e
+    json.dump({"command": command, "per_launch_means": kernels}, open(out, "w"), indent=1)
+    print(json.dumps(kernels.get("icp_persistent_kernel"), indent=1))
+
+
+if __name__ == "__main__":
+    main()

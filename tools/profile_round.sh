@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 passes behind profiles/<tag>_*: run on the GPU box from the repository root,  bash tools/profile_round.sh r1b
+# One pass per counter group (MI355X_MICROARCH.md, HBM section); results land in gpurun_out/<tag>_*.
+set -e
+tag=${1:-r1}
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+B="python3 bench.py --no-cpu-baseline --streams 0"
+timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o s -- $B --steps 100 --warmup 20 > gpurun_out/${tag}_stats.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc_fetch -o f -- $B --steps 20 --warmup 10 > gpurun_out/${tag}_pmc_fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pmc_write -o w -- $B --steps 20 --warmup 10 > gpurun_out/${tag}_pmc_write.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES SQ_INSTS_SALU SQ_BUSY_CYCLES TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/${tag}_pmc_sq -o q -- $B --steps 20 --warmup 10 > gpurun_out/${tag}_pmc_sq.log 2>&1
+find gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_sq -name "*.csv" | sort
