@@ -565,9 +565,24 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     const int label0 = src.l[qs];
     const int n = *n_ptr;
     if (mirror && blockIdx.x == 0 && threadIdx.x == 0) mirror->t_icp_start = wall_clock64();
-    Rigid T_total = st->T_total;
-    const double max_corr = st->max_corr, th = st->kernel_th;
-    const int max_iter = st->icp_max_iter;
+    // the registration state: left in DevState by icp_init_kernel, or - a launch chained behind a map update, with
+    // no dispatch in between - written into the host mirror by the host
+    const bool host_init = mirror && mirror->init_enabled != 0;
+    Rigid T_total;
+    double max_corr, th;
+    int max_iter;
+    uint32_t ticket_base = 0;
+    if (host_init) {
+        T_total = Rigid{mirror->init_guess[0], mirror->init_guess[1], mirror->init_guess[2], mirror->init_guess[3],
+                        D3{mirror->init_guess[4], mirror->init_guess[5], mirror->init_guess[6]}};
+        max_corr = mirror->init_max_corr; th = mirror->init_kernel_th;
+        max_iter = mirror->init_max_iter;
+        ticket_base = mirror->init_ticket_base;
+    } else {
+        T_total = st->T_total;
+        max_corr = st->max_corr; th = st->kernel_th;
+        max_iter = st->icp_max_iter;
+    }
     const SearchConst sc = search_const(m);
     const double max_corr2 = max_corr * max_corr, th2 = th * th;
     const bool plain = th < 0.0;  // no robust kernel, no class weight (loopclosure/FastIcp.cpp:146-152)
@@ -580,7 +595,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     __shared__ long long s_cnt[3];   // correspondences, candidates, probes summed over the iterations
     __shared__ int s_flag;  // after the wait: 1 = abort; after the solve: 1 = converged
     if (threadIdx.x == 0) {
-        s_T[0] = st->T_icp;
+        s_T[0] = host_init ? rigid_identity() : st->T_icp;
         s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
     }
     int it = 0;
@@ -641,7 +656,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
             if (lane == 0)
                 __hip_atomic_fetch_add(&tickets[(blockIdx.x % kIcpTickets) * kIcpTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t share = gridDim.x / kIcpTickets + ((uint32_t)lane < gridDim.x % kIcpTickets ? 1u : 0u);
-            const uint32_t target = (uint32_t)(it + 1) * share;
+            const uint32_t target = (ticket_base + (uint32_t)(it + 1)) * share;
             const bool watcher = lane < kIcpTickets;
             int abort = 0;
             for (uint32_t spins = 0;; ++spins) {
@@ -702,6 +717,11 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     }
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const long long corr = s_cnt[0], cand = s_cnt[1], probe = s_cnt[2];
+    if (mirror && mirror->init_enabled != 0) {  // what icp_init_kernel would have left
+        const int32_t *z = mirror->init_sizes4;
+        if (z) { st->n_in = z[0]; st->n_c = z[1]; st->n_d = z[2]; st->n_s = z[3]; }
+        st->max_corr = max_corr; st->kernel_th = th; st->icp_max_iter = max_iter;
+    }
     st->T_icp = s_T[0];
     st->T_total = T_total;
     st->icp_corr = corr; st->icp_cand = cand; st->icp_probe = probe;

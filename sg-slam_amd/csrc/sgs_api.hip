@@ -176,6 +176,8 @@ struct sgs_ctx {
     // icp
     double *partials = nullptr, *out28 = nullptr;
     uint32_t *tickets = nullptr;  // arrival counters of the one-launch Gauss-Newton loop (zeroed by icp_init)
+    uint32_t ticket_base = 0;     // iterations counted on them since they were last zeroed (host-initialised launches)
+    bool tickets_dirty = false;   // a launch gave up: the counters hold its abort mark
     double *corr_tgt = nullptr;
     int32_t *corr_found = nullptr;
     // state
@@ -479,7 +481,32 @@ int run_icp_per_launch(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *ite
 }
 
 // the whole loop in one launch: enqueue ...
-int icp_persistent_launch(sgs_ctx *c, CloudView src, const int32_t *n_ptr) {
+// what icp_init_kernel would set, for a launch that reads it from the host mirror instead (one dispatch less)
+struct HostInit {
+    Rigid guess;
+    double max_corr, kernel_th;
+    const int32_t *sizes4;
+};
+int icp_persistent_launch(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const HostInit *hi = nullptr) {
+    HostMirror *mi = c->mirror;
+    if (hi) {
+        if (c->tickets_dirty || c->ticket_base > (1u << 26)) {
+            SGS_HIP(c, hipMemsetAsync(c->tickets, 0, sizeof(uint32_t) * kIcpTicketWords, c->stream));
+            c->tickets_dirty = false;
+            c->ticket_base = 0;
+        }
+        mi->init_guess[0] = hi->guess.qw; mi->init_guess[1] = hi->guess.qx; mi->init_guess[2] = hi->guess.qy; mi->init_guess[3] = hi->guess.qz;
+        mi->init_guess[4] = hi->guess.t.x; mi->init_guess[5] = hi->guess.t.y; mi->init_guess[6] = hi->guess.t.z;
+        mi->init_max_corr = hi->max_corr; mi->init_kernel_th = hi->kernel_th;
+        mi->init_max_iter = kIcpMaxIter;
+        mi->init_sizes4 = hi->sizes4;
+        mi->init_ticket_base = c->ticket_base;
+        mi->init_enabled = 1;
+    } else {
+        mi->init_enabled = 0;  // icp_init_kernel has been enqueued in front: it zeroes the counters
+        c->ticket_base = 0;
+        c->tickets_dirty = false;
+    }
     volatile int32_t *mb = &c->mirror->icp_iter;
     mb[0] = 0;
     mb[1] = 0;
@@ -523,11 +550,13 @@ int icp_persistent_wait(sgs_ctx *c, int *iters_out, bool *fell_back) {
     if (done == 2) {  // the kernel gave up waiting for its other blocks
         SGS_HIP(c, hipStreamSynchronize(c->stream));
         *fell_back = true;
+        c->tickets_dirty = true;
         c->stats.icp_fallbacks++;
         if (c->profiling) c->icp_events_used--;
         return SGS_OK;
     }
     *iters_out = __atomic_load_n(&mb[0], __ATOMIC_ACQUIRE);
+    c->ticket_base += (uint32_t)*iters_out;
     return SGS_OK;
 }
 int run_icp_persistent(sgs_ctx *c, CloudView src, const int32_t *n_ptr, int *iters_out, bool *fell_back) {
@@ -804,8 +833,8 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     };
     if (ahead) {
         if (!chained) {
-            launch_icp_init(s, c->st, guess, 3.0 * sigma, sigma / 3.0, kIcpMaxIter, S.sizes, c->tickets);
-            if ((r = icp_persistent_launch(c, S.src, S.sizes + 3))) return r;
+            const HostInit hi{guess, 3.0 * sigma, sigma / 3.0, S.sizes};
+            if ((r = icp_persistent_launch(c, S.src, S.sizes + 3, &hi))) return r;
         }
         if ((r = enqueue_map_update(true))) return r;
         const uint64_t fb0 = c->stats.icp_fallbacks;
@@ -868,8 +897,8 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
             next_scan_params(c, &c->next_guess, &c->next_sigma);
             c->next_params_valid = true;
             if (hipEventQuery(Nx.ev_front) != hipSuccess) SGS_HIP(c, hipStreamWaitEvent(s, Nx.ev_front, 0));  // usually long done
-            launch_icp_init(s, c->st, c->next_guess, 3.0 * c->next_sigma, c->next_sigma / 3.0, kIcpMaxIter, Nx.sizes, c->tickets);
-            if ((r = icp_persistent_launch(c, Nx.src, Nx.sizes + 3))) return r;
+            const HostInit hi{c->next_guess, 3.0 * c->next_sigma, c->next_sigma / 3.0, Nx.sizes};
+            if ((r = icp_persistent_launch(c, Nx.src, Nx.sizes + 3, &hi))) return r;
             c->chained_set = c->cur ^ 1;
             if (c->trace) { c->tr_chained++; c->tr_host_done_to_chain += now_ms() - t_icp_done; }
         }
@@ -1004,9 +1033,9 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     if (hipStreamCreateWithFlags(&c->streamF, hipStreamNonBlocking) != hipSuccess) return bail(SGS_EHIP);
     if (hipEventCreate(&c->ev_g0) != hipSuccess || hipEventCreate(&c->ev_g1) != hipSuccess) return bail(SGS_EHIP);
     for (ScanSet &S : c->sets)
-        if (hipEventCreateWithFlags(&S.ev_ds, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&S.ev_front, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&S.ev_free, hipEventDisableTiming) != hipSuccess)
+        if (hipEventCreateWithFlags(&S.ev_ds, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+            hipEventCreateWithFlags(&S.ev_front, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+            hipEventCreateWithFlags(&S.ev_free, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
             return bail(SGS_EHIP);
     if (hipHostMalloc((void **)&c->mirror, sizeof(HostMirror), hipHostMallocMapped) != hipSuccess) return bail(SGS_ENOMEM);
     if (hipHostGetDevicePointer((void **)&c->mirror_dev, c->mirror, 0) != hipSuccess) return bail(SGS_EHIP);

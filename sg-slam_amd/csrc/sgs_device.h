@@ -100,6 +100,13 @@ struct HostMirror {
     int32_t map_live, map_tomb, map_points, map_err_flags;  // written by every map sweep (census)
     int32_t census_seq, pad1;
     int32_t icp_map_live, icp_map_tomb, icp_map_points, pad2;  // census of the map the registration ran against
+    // host -> device: registration parameters written by the HOST before a launch of the one-launch loop that
+    // has no icp_init kernel in front of it (init_enabled != 0); the kernel reads them over the bus at its start
+    int32_t init_enabled, init_max_iter;
+    uint32_t init_ticket_base, pad3;  // iterations already counted on the arrival counters (they are not re-zeroed)
+    double init_guess[7];             // qw, qx, qy, qz, tx, ty, tz
+    double init_max_corr, init_kernel_th;
+    const int32_t *init_sizes4;       // device int32[4] of the scan: n_in, n_c, n_d, n_s
     // device timestamps (wall_clock64, 100 MHz) for SGS_TRACE=1: start / end of the one-launch Gauss-Newton
     // kernel and end of the map update's census kernel
     unsigned long long t_icp_start, t_icp_end, t_census_end;
