@@ -568,6 +568,11 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     // the registration state: left in DevState by icp_init_kernel, or - a launch chained behind a map update, with
     // no dispatch in between - written into the host mirror by the host
     const bool host_init = mirror && mirror->init_enabled != 0;
+    if (host_init && mirror->init_enabled == 2) {  // test hook (SGS_TEST_ABORT_EVERY): behave as if the inter-block wait ran out
+        if (threadIdx.x == 0 && blockIdx.x == 0) st->icp_abort = 1;
+        if (threadIdx.x == 0) __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     Rigid T_total;
     double max_corr, th;
     int max_iter;

@@ -178,6 +178,7 @@ struct sgs_ctx {
     uint32_t *tickets = nullptr;  // arrival counters of the one-launch Gauss-Newton loop (zeroed by icp_init)
     uint32_t ticket_base = 0;     // iterations counted on them since they were last zeroed (host-initialised launches)
     bool tickets_dirty = false;   // a launch gave up: the counters hold its abort mark
+    int test_abort_every = 0, test_abort_count = 0;  // SGS_TEST_ABORT_EVERY=n: every n-th host-initialised launch gives up at once
     double *corr_tgt = nullptr;
     int32_t *corr_found = nullptr;
     // state
@@ -502,6 +503,7 @@ int icp_persistent_launch(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const
         mi->init_sizes4 = hi->sizes4;
         mi->init_ticket_base = c->ticket_base;
         mi->init_enabled = 1;
+        if (c->test_abort_every > 0 && ++c->test_abort_count % c->test_abort_every == 0) mi->init_enabled = 2;
     } else {
         mi->init_enabled = 0;  // icp_init_kernel has been enqueued in front: it zeroes the counters
         c->ticket_base = 0;
@@ -1073,6 +1075,8 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     {
         const char *e = getenv("SGS_ICP_PER_LAUNCH");
         c->icp_persistent = !(e && e[0] == '1');
+        const char *ab = getenv("SGS_TEST_ABORT_EVERY");
+        c->test_abort_every = ab ? atoi(ab) : 0;
         const char *t = getenv("SGS_TRACE");
         c->trace = t && t[0] == '1';
     }

@@ -772,3 +772,44 @@ def test_scan_descriptor_of_the_last_processed_scan():
         want = O.scan_descriptor(slam.boxes(), cx, cl)
         assert np.array_equal(ctx.scan_descriptor(), want)
     ctx.close()
+
+
+def test_pipeline_survives_a_one_launch_loop_that_gives_up(monkeypatch):
+    """Every 3rd chained / ahead-of-time launch is made to give up at once (SGS_TEST_ABORT_EVERY): the map update
+    queued behind it must skip itself, registration and update are repeated with one launch per iteration, and
+    nothing in the results may change."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    scans = [synth.scan(k, "small") for k in range(14)]
+    n = len(scans[0][0])
+
+    def dev(a):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(p, ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 1) == 0
+        return p
+    d_x = [dev(np.ascontiguousarray(s[0], dtype=np.float32)) for s in scans]
+    d_l = [dev(np.ascontiguousarray(s[2], dtype=np.int32)) for s in scans]
+
+    def run():
+        ctx = make_ctx(async_map_update=1)
+        res = api.SgsScanResult()
+        out = []
+        for k in range(len(scans)):
+            if k + 1 < len(scans):
+                ctx.prefetch_scan_dev(d_x[k + 1].value, d_l[k + 1].value, n, "")
+            ctx.process_scan_dev(d_x[k].value, d_l[k].value, n, None, "", res)
+            out.append((np.array(res.pose[:]), res.icp_iterations, res.n_src, res.n_boxes, res.map_voxels))
+        st = ctx.stats()
+        voxels = ctx.map_size()
+        ctx.close()
+        return out, st.icp_fallbacks, voxels
+    ref, fb0, vox0 = run()
+    monkeypatch.setenv("SGS_TEST_ABORT_EVERY", "3")
+    got, fb1, vox1 = run()
+    assert fb0 == 0 and fb1 >= 3
+    assert vox0 == vox1
+    for a, b in zip(ref, got):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    for p in d_x + d_l:
+        hip.hipFree(p)
