@@ -85,6 +85,18 @@ def lib():
         L.sgo_scan_descriptor.argtypes = [c_vp, c_int, c_vp, c_vp, c_int, c_dbl, c_int, c_vp]
         L.sgo_fast_atan2.restype = c_dbl
         L.sgo_fast_atan2.argtypes = [c_dbl, c_dbl]
+        L.sgo_graphmap_create.restype = c_vp
+        L.sgo_graphmap_create.argtypes = [c_dbl, c_dbl, c_int, c_int, c_dbl, c_dbl, c_dbl]
+        L.sgo_graphmap_destroy.restype = None
+        L.sgo_graphmap_destroy.argtypes = [c_vp]
+        L.sgo_graphmap_track.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
+        L.sgo_graphmap_instances.argtypes = [c_vp, c_vp, c_int]
+        L.sgo_graphmap_relocalize.argtypes = [c_vp, c_vp, c_int, c_dbl, ctypes.c_uint32, c_vp, c_vp, c_vp]
+        L.sgo_solve_svd.restype = None
+        L.sgo_solve_svd.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp]
+        L.sgo_ransac_alignment.argtypes = [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, ctypes.c_uint32, c_vp, c_vp, c_vp]
+        L.sgo_slam_graphmap_info.restype = None
+        L.sgo_slam_graphmap_info.argtypes = [c_vp, c_vp]
         L.sgo_voxel_keys.restype = None
         L.sgo_voxel_keys.argtypes = [c_vp, c_int, c_dbl, c_vp]
         L.sgo_preprocess.argtypes = [c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]
@@ -296,6 +308,52 @@ def fast_icp(xyzl_a, xyzl_b, init7, voxel_size_map=1.0, max_points_per_voxel=5, 
     return out, dict(iterations=int(info[0]), candidates=int(info[1]), correspondences=int(info[2]))
 
 
+def solve_svd(p1, p2):
+    """core/CommonUtils.cpp:264-316 -> (R 3x3, t) with R @ p1 + t ~ p2."""
+    a = _f64(p1); b = _f64(p2); R = np.empty((3, 3)); t = np.empty(3)
+    lib().sgo_solve_svd(a.ctypes.data, b.ctypes.data, len(a), R.ctypes.data, t.ctypes.data)
+    return R, t
+
+
+def ransac_alignment(m1, m2, nodes1, nodes2, max_iter=500, seed=1):
+    """core/CommonUtils.cpp:115-204 with a seeded engine -> (R, t, score, best_inlier)."""
+    a = _f64(m1); b = _f64(m2); n1 = _f64(nodes1); n2 = _f64(nodes2); R = np.empty((3, 3)); t = np.empty(3); sc = c_dbl()
+    best = lib().sgo_ransac_alignment(a.ctypes.data, b.ctypes.data, len(a), n1.ctypes.data, len(n1), n2.ctypes.data, len(n2),
+                                      int(max_iter), int(seed), R.ctypes.data, t.ctypes.data, ctypes.byref(sc))
+    return R, t, sc.value, best
+
+
+class GraphMap:
+    """frontend/GraphMap.{hpp,cpp}: the local map of tracked instances."""
+
+    def __init__(self, edge_dis_th=60.0, subgraph_edge_th=20.0, subinterval=30, dim=30, nn_vehicle=2.0, nn_pole=2.0, max_distance=100.0):
+        self.h = lib().sgo_graphmap_create(edge_dis_th, subgraph_edge_th, subinterval, dim, nn_vehicle, nn_pole, max_distance)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().sgo_graphmap_destroy(self.h)
+            self.h = None
+
+    def track(self, boxes, pose7):
+        """BuildGraph -> FindInsMatch -> Update; -> (matches (nb, 3) [flag, frame id, map id], new_instance ids)."""
+        b = _f64(boxes).reshape(-1, 8); p = _f64(pose7); nb = len(b)
+        m = np.zeros((max(nb, 1), 3), dtype=np.int32); fresh = np.zeros(max(nb, 1), dtype=np.int32); nn = ctypes.c_int32()
+        n = lib().sgo_graphmap_track(self.h, b.ctypes.data, nb, p.ctypes.data, m.ctypes.data, fresh.ctypes.data, ctypes.byref(nn))
+        return m[:n].copy(), fresh[:nn.value].copy()
+
+    def instances(self):
+        n = lib().sgo_graphmap_instances(self.h, None, 0)
+        out = np.empty((max(n, 1), 9))
+        lib().sgo_graphmap_instances(self.h, out.ctypes.data, n)
+        return out[:n].copy()
+
+    def relocalize(self, boxes, inlier_rate_th=0.4, seed=1):
+        b = _f64(boxes).reshape(-1, 8); pose = np.empty(7); sc = c_dbl(); nm = ctypes.c_int32()
+        ok = lib().sgo_graphmap_relocalize(self.h, b.ctypes.data, len(b), float(inlier_rate_th), int(seed), pose.ctypes.data,
+                                           ctypes.byref(sc), ctypes.byref(nm))
+        return bool(ok), pose, sc.value, nm.value
+
+
 def scan_descriptor(boxes, xyz, label, edge_dis_th=60.0, subinterval=30):
     """loopclosure/LoopClosure.cpp:15-32 GenScanDescriptors on the boxes + the 0.2 m cluster cloud of a scan."""
     boxes = _f64(boxes).reshape(-1, 8); xyz = _f64(xyz); label = _i32(label)
@@ -359,6 +417,11 @@ class Slam:
                     n_ds=int(counts[2]), n_src=int(counts[3]), n_boxes=int(counts[4]),
                     iterations=int(counts[5]), map_voxels=int(counts[6]), correspondences=int(counts[7]),
                     candidates=cand.value, stage_ms=ms)
+
+    def graphmap_info(self):
+        info = np.zeros(4, dtype=np.int64)
+        lib().sgo_slam_graphmap_info(self.h, info.ctypes.data)
+        return dict(instances=int(info[0]), attempts=int(info[1]), relocalizations=int(info[2]), relocalized=bool(info[3]))
 
     def cloud(self, which):
         n = lib().sgo_slam_get_cloud(self.h, which, None, None, 0)

@@ -342,6 +342,80 @@ void sgo_slam_process(void *hh, const double *xyz, const int32_t *label, int n, 
     if (stage_ms) std::memcpy(stage_ms, o.stage_ms, sizeof(double) * 8);
     if (candidates) *candidates = o.icp.candidates;
 }
+// relocalization bookkeeping of the pipeline: [instances in the local graph map, relocalization attempts, successes, last scan relocalized]
+void sgo_slam_graphmap_info(void *hh, int64_t *info4) {
+    auto *h = (SlamHandle *)hh;
+    info4[0] = (int64_t)h->slam.local_graph_map_.instance_in_localmap.size();
+    info4[1] = h->slam.relocalization_attempts;
+    info4[2] = h->slam.relocalizations;
+    info4[3] = h->last.relocalized ? 1 : 0;
+}
+
+// ---- GraphMap / relocalization pieces (frontend/GraphMap.cpp, core/CommonUtils.cpp) ----
+void *sgo_graphmap_create(double edge_dis_th, double subgraph_edge_th, int subinterval, int dim, double nn_vehicle, double nn_pole,
+                          double max_distance) {
+    return new GraphMap(edge_dis_th, subgraph_edge_th, subinterval, dim, nn_vehicle, nn_pole, max_distance);
+}
+void sgo_graphmap_destroy(void *h) { delete (GraphMap *)h; }
+static Graph frame_graph_of(const GraphMap &g, const double *boxes, int nb) {
+    return build_graph(boxes_in(boxes, nb), g.edge_dis_th_, g.subinterval_, g.graph_node_dimension_, g.subgraph_edge_th_);
+}
+// BuildGraph(boxes) -> FindInsMatch -> Update(pose): what mainProcess does per scan (SemGraphSLAM.cpp:49,54,116).
+// matches: nb rows [flag, frame id, map id] in the reference's order (matched first); new_instance: frame ids
+int sgo_graphmap_track(void *hh, const double *boxes, int nb, const double *pose7, int32_t *matches, int32_t *new_instance, int32_t *n_new) {
+    auto *h = (GraphMap *)hh;
+    const Graph g = frame_graph_of(*h, boxes, nb);
+    const std::vector<InsMatch> m = h->FindInsMatch(g);
+    std::vector<int> fresh;
+    h->Update(g, m, pose_in(pose7), &fresh);
+    for (size_t i = 0; i < m.size(); ++i) {
+        matches[3 * i] = m[i].flag ? 1 : 0; matches[3 * i + 1] = m[i].frame_id; matches[3 * i + 2] = m[i].map_id;
+    }
+    for (size_t i = 0; i < fresh.size(); ++i) new_instance[i] = fresh[i];
+    if (n_new) *n_new = (int32_t)fresh.size();
+    return (int)m.size();
+}
+// rows of 9 doubles: label, id, pose xyz, dimension xyz, points
+int sgo_graphmap_instances(void *hh, double *out, int cap) {
+    auto *h = (GraphMap *)hh;
+    const int n = (int)h->instance_in_localmap.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        const InsNode &v = h->instance_in_localmap[(size_t)i];
+        double *o = out + 9 * (size_t)i;
+        o[0] = v.label; o[1] = v.id; o[2] = v.pose.x; o[3] = v.pose.y; o[4] = v.pose.z;
+        o[5] = v.dimension.x; o[6] = v.dimension.y; o[7] = v.dimension.z; o[8] = v.points_num;
+    }
+    return n;
+}
+// FindInsMatch + Relocalization of a frame given by its boxes (in the sensor frame); returns the success flag
+int sgo_graphmap_relocalize(void *hh, const double *boxes, int nb, double inlier_rate_th, uint32_t seed, double *pose7, double *score,
+                            int32_t *n_matched) {
+    auto *h = (GraphMap *)hh;
+    const Graph g = frame_graph_of(*h, boxes, nb);
+    const std::vector<InsMatch> m = h->FindInsMatch(g);
+    int nm = 0;
+    for (const InsMatch &x : m) nm += x.flag ? 1 : 0;
+    if (n_matched) *n_matched = nm;
+    const auto r = h->Relocalization(g, m, inlier_rate_th, seed, score);
+    pose_out(r.first, pose7);
+    return r.second ? 1 : 0;
+}
+void sgo_solve_svd(const double *p1, const double *p2, int n, double *R9, double *t3) {
+    const Iso3 T = solve_svd(vec3_in(p1, n), vec3_in(p2, n));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R9[3 * i + j] = T.R.m[i][j];
+    t3[0] = T.t.x; t3[1] = T.t.y; t3[2] = T.t.z;
+}
+int sgo_ransac_alignment(const double *m1, const double *m2, int nm, const double *nodes1, int n1, const double *nodes2, int n2, int max_iter,
+                         uint32_t seed, double *R9, double *t3, double *score) {
+    int best = 0;
+    const auto r = ransac_alignment(vec3_in(m1, nm), vec3_in(m2, nm), vec3_in(nodes1, n1), vec3_in(nodes2, n2), max_iter, seed, &best);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R9[3 * i + j] = r.first.R.m[i][j];
+    t3[0] = r.first.t.x; t3[1] = r.first.t.y; t3[2] = r.first.t.z;
+    if (score) *score = r.second;
+    return best;
+}
 // which: 0 cropped, 1 cluster cloud, 2 frame_downsample, 3 source
 int sgo_slam_get_cloud(void *hh, int which, double *xyz, int32_t *label, int cap) {
     auto *h = (SlamHandle *)hh;

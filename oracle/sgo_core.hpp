@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <numeric>
+#include <random>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -844,6 +845,357 @@ inline std::vector<float> gen_scan_descriptors(const std::vector<Bbox> &boxes, c
     return d;
 }
 
+// ---- frontend/GraphMap.{hpp,cpp} + core/CommonUtils.cpp: instance tracking and relocalization ----
+struct InsNode {  // core/Coreutils.h:81-87
+    int label = 0, id = 0;
+    Vec3 pose, dimension;
+    int points_num = 0;
+};
+struct InsMatch {  // one entry of VTbii (GraphMap.hpp:23): (match flag, id in the frame graph, id in the local map)
+    bool flag;
+    int frame_id, map_id;
+};
+// GraphMap.cpp:11-40
+inline bool check_sub_triangle(const std::vector<Vec3> &t1, const std::vector<Vec3> &t2) {
+    int matched = 0;
+    if (t1.size() < 2 && t2.size() < 2) return true;
+    for (const Vec3 &a : t1)
+        for (const Vec3 &b : t2)
+            if (std::abs(a.x - b.x) < 0.3 && std::abs(a.y - b.y) < 0.3 && std::abs(a.z - b.z) < 0.3) matched++;
+    if (t1.size() > 5 && t2.size() > 5) return matched >= 3;
+    return matched >= 1;
+}
+// squared L2 distance as nanoflann's L2_Adaptor accumulates it (core/nanoflann.hpp, float, four terms at a time)
+inline float desc_dist2(const std::vector<float> &a, const std::vector<float> &b) {
+    float result = 0.f;
+    size_t d = 0;
+    const size_t n = a.size();
+    while (d + 3 < n) {
+        const float d0 = a[d] - b[d], d1 = a[d + 1] - b[d + 1], d2 = a[d + 2] - b[d + 2], d3 = a[d + 3] - b[d + 3];
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        d += 4;
+    }
+    while (d < n) {
+        const float d0 = a[d] - b[d];
+        result += d0 * d0;
+        ++d;
+    }
+    return result;
+}
+// GraphMap.cpp:43-82 FindCorrespondencesKDtree: the 5 nearest map nodes in descriptor space (exact search, so a
+// sorted brute-force scan gives the kd-tree's answer; equal distances keep the lower index), first one with the
+// same label and a compatible sub-triangle set wins.  With fewer than 5 map nodes the unused result slots of the
+// reference stay at index 0.
+inline std::vector<std::pair<int, int>> find_correspondences_knn(const Graph &frame, const Graph &map, int k) {
+    std::vector<std::pair<int, int>> out;
+    const int M = (int)map.node_desc.size();
+    for (int i = 0; i < (int)frame.node_desc.size(); ++i) {
+        std::vector<std::pair<float, int>> d((size_t)M);
+        for (int j = 0; j < M; ++j) d[(size_t)j] = {desc_dist2(frame.node_desc[(size_t)i], map.node_desc[(size_t)j]), j};
+        std::stable_sort(d.begin(), d.end(), [](const std::pair<float, int> &a, const std::pair<float, int> &b) { return a.first < b.first; });
+        for (int m = 0; m < k; ++m) {
+            const int j = m < M ? d[(size_t)m].second : 0;
+            if (frame.node_labels[(size_t)i] == map.node_labels[(size_t)j] &&
+                check_sub_triangle(frame.node_sub_triangles[(size_t)i], map.node_sub_triangles[(size_t)j])) {
+                out.emplace_back(i, j);
+                break;
+            }
+        }
+    }
+    return out;
+}
+// CommonUtils.cpp:264-316 SolveSVD: Kabsch on the centred pairs, R = V E U^T.  The 3x3 SVD is taken from the
+// eigen-decomposition of W^T W (cyclic Jacobi); a rank-deficient W (three points are always coplanar after
+// centring) has its missing directions completed by cross products - the determinant rule then fixes the sign,
+// so every completion gives the same R.  Fewer than two independent directions (repeated sample indices) has no
+// defined answer in the reference either (whatever JacobiSVD leaves); here it returns R = I.
+inline void jacobi3(double A[3][3], double V[3][3], double w[3]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::abs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) w[i] = A[i][i];
+}
+struct Iso3 {  // Eigen::Isometry3d as rotation matrix + translation
+    Mat3 R;
+    Vec3 t;
+};
+inline Iso3 solve_svd(const std::vector<Vec3> &n1, const std::vector<Vec3> &n2) {
+    const int N = (int)n1.size();
+    Vec3 s1(0, 0, 0), s2(0, 0, 0);
+    for (int i = 0; i < N; ++i) { s1 = s1 + n1[(size_t)i]; s2 = s2 + n2[(size_t)i]; }
+    const Vec3 m1 = s1 / (double)N, m2 = s2 / (double)N;
+    double W[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int i = 0; i < N; ++i) {
+        const Vec3 a = n1[(size_t)i] - m1, b = n2[(size_t)i] - m2;
+        const double av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) W[r][c] += av[r] * bv[c];
+    }
+    double WtW[3][3], V[3][3], ev[3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) WtW[r][c] = W[0][r] * W[0][c] + W[1][r] * W[1][c] + W[2][r] * W[2][c];
+    jacobi3(WtW, V, ev);
+    int ord[3] = {0, 1, 2};
+    std::sort(ord, ord + 3, [&](int a, int b) { return ev[a] > ev[b]; });
+    Vec3 v[3], u[3];
+    for (int k = 0; k < 3; ++k) v[k] = Vec3(V[0][ord[k]], V[1][ord[k]], V[2][ord[k]]);
+    const double smax = std::sqrt(std::max(ev[ord[0]], 0.0));
+    int rank = 0;
+    for (int k = 0; k < 3; ++k) {
+        const double sv = std::sqrt(std::max(ev[ord[k]], 0.0));
+        if (sv > 1e-9 * smax && sv > 1e-150) {
+            const Vec3 wv(W[0][0] * v[k].x + W[0][1] * v[k].y + W[0][2] * v[k].z, W[1][0] * v[k].x + W[1][1] * v[k].y + W[1][2] * v[k].z,
+                          W[2][0] * v[k].x + W[2][1] * v[k].y + W[2][2] * v[k].z);
+            u[k] = wv / sv;
+            rank = k + 1;
+        } else {
+            break;
+        }
+    }
+    Iso3 T;
+    if (rank < 2) {
+        T.R = Mat3();
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) T.R.m[i][j] = i == j ? 1.0 : 0.0;
+    } else {
+        if (rank == 2) {
+            u[2] = cross(u[0], u[1]);
+            v[2] = cross(v[0], v[1]);
+        }
+        // R = V E U^T with E = diag(1, 1, det(V U^T))
+        auto build = [&](double e) {
+            Mat3 R;
+            const double vv[3][3] = {{v[0].x, v[1].x, v[2].x}, {v[0].y, v[1].y, v[2].y}, {v[0].z, v[1].z, v[2].z}};
+            const double uu[3][3] = {{u[0].x, u[1].x, u[2].x}, {u[0].y, u[1].y, u[2].y}, {u[0].z, u[1].z, u[2].z}};
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) R.m[r][c] = vv[r][0] * uu[c][0] + vv[r][1] * uu[c][1] + e * vv[r][2] * uu[c][2];
+            return R;
+        };
+        Mat3 R = build(1.0);
+        const double det = R.m[0][0] * (R.m[1][1] * R.m[2][2] - R.m[1][2] * R.m[2][1]) - R.m[0][1] * (R.m[1][0] * R.m[2][2] - R.m[1][2] * R.m[2][0]) +
+                           R.m[0][2] * (R.m[1][0] * R.m[2][1] - R.m[1][1] * R.m[2][0]);
+        if (det < 0) R = build(-1.0);
+        T.R = R;
+    }
+    T.t = m2 - T.R * m1;
+    return T;
+}
+// CommonUtils.cpp:115-204 RansacAlignment(match1, match2, graph1, graph2, max_iter, best_inlier): random triplets of
+// the matches, inliers = frame nodes that land within one 0.2 m voxel (held in a float) of some map node.
+// std::random_device in the reference; a caller-given seed here (same engine and distribution).
+inline std::pair<Iso3, double> ransac_alignment(const std::vector<Vec3> &m1, const std::vector<Vec3> &m2, const std::vector<Vec3> &nodes1,
+                                                const std::vector<Vec3> &nodes2, int max_iter, uint32_t seed, int *best_inlier) {
+    std::mt19937 gen(seed);
+    std::uniform_int_distribution<> dis(0, (int)m1.size() - 1);
+    Iso3 final_T;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) final_T.R.m[i][j] = i == j ? 1.0 : 0.0;
+    final_T.t = Vec3(0, 0, 0);
+    const float voxel_size = 0.2f;
+    RobinMap<int> occupied;
+    for (const Vec3 &p : nodes2) {
+        const Key3 k{(int)(p.x / voxel_size), (int)(p.y / voxel_size), (int)(p.z / voxel_size)};
+        if (occupied.find(k) < 0) occupied.insert(k, 1);
+    }
+    for (int it = 0; it < max_iter; ++it) {
+        const int i1 = dis(gen), i2 = dis(gen), i3 = dis(gen);
+        const Iso3 T = solve_svd({m1[(size_t)i1], m1[(size_t)i2], m1[(size_t)i3]}, {m2[(size_t)i1], m2[(size_t)i2], m2[(size_t)i3]});
+        int inliers = 0;
+        for (const Vec3 &p : nodes1) {
+            const Vec3 q = T.R * p + T.t;
+            const int kx = (int)(q.x / voxel_size), ky = (int)(q.y / voxel_size), kz = (int)(q.z / voxel_size);
+            bool hit = false;
+            for (int a = kx - 1; a <= kx + 1 && !hit; ++a)
+                for (int b = ky - 1; b <= ky + 1 && !hit; ++b)
+                    for (int c = kz - 1; c <= kz + 1 && !hit; ++c) hit = occupied.find(Key3{a, b, c}) >= 0;
+            if (hit) inliers++;
+        }
+        if (inliers > *best_inlier) {
+            *best_inlier = inliers;
+            final_T = T;
+        }
+    }
+    const double score = (float)*best_inlier / nodes1.size();
+    return {final_T, score};
+}
+// Eigen's Quaternion(Matrix3) (what Sophus::SE3d(Matrix4d) does to the rotation part)
+inline Quat quat_from_matrix(const Mat3 &R) {
+    Quat q;
+    const double t = R.m[0][0] + R.m[1][1] + R.m[2][2];
+    if (t > 0) {
+        double s = std::sqrt(t + 1.0);
+        q.w = 0.5 * s;
+        s = 0.5 / s;
+        q.x = (R.m[2][1] - R.m[1][2]) * s; q.y = (R.m[0][2] - R.m[2][0]) * s; q.z = (R.m[1][0] - R.m[0][1]) * s;
+    } else {
+        int i = 0;
+        if (R.m[1][1] > R.m[0][0]) i = 1;
+        if (R.m[2][2] > R.m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = std::sqrt(R.m[i][i] - R.m[j][j] - R.m[k][k] + 1.0);
+        double v[3];
+        v[i] = 0.5 * s;
+        s = 0.5 / s;
+        q.w = (R.m[k][j] - R.m[j][k]) * s;
+        v[j] = (R.m[j][i] + R.m[i][j]) * s;
+        v[k] = (R.m[k][i] + R.m[i][k]) * s;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    normalize(q);
+    return q;
+}
+inline Graph build_graph(const std::vector<Bbox> &, double, int, int, double);
+struct GraphMap {  // GraphMap.hpp:28-71
+    int instance_id_ = 0;
+    double voxel_size_ = 1.5;
+    double edge_dis_th_, subgraph_edge_th_;
+    int subinterval_, graph_node_dimension_;
+    double nn_vehicle_, nn_pole_, max_distance_;
+    Graph InsGraphMap;
+    std::vector<InsNode> instance_in_localmap;
+    GraphMap(double edge_dis_th, double subgraph_edge_th, int subinterval, int dim, double nn_vehicle, double nn_pole, double max_distance)
+        : edge_dis_th_(edge_dis_th), subgraph_edge_th_(subgraph_edge_th), subinterval_(subinterval), graph_node_dimension_(dim),
+          nn_vehicle_(nn_vehicle), nn_pole_(nn_pole), max_distance_(max_distance) {}
+    // GraphMap.cpp:88-113
+    std::vector<InsMatch> FindInsMatch(const Graph &graph) const {
+        std::vector<InsMatch> out;
+        if (InsGraphMap.node_labels.empty()) {
+            for (int i = 0; i < (int)graph.node_labels.size(); ++i) out.push_back({false, i, -1});
+            return out;
+        }
+        const auto corr = find_correspondences_knn(graph, InsGraphMap, 5);
+        std::vector<bool> is_match(graph.node_labels.size(), false);
+        for (const auto &c : corr) {
+            out.push_back({true, c.first, c.second});
+            is_match[(size_t)c.first] = true;
+        }
+        for (int i = 0; i < (int)is_match.size(); ++i)
+            if (!is_match[(size_t)i]) out.push_back({false, i, -1});
+        return out;
+    }
+    // GraphMap.cpp:227-262
+    bool IsExistNearestNeighbor(const RobinMap<std::vector<int>> &hash, const Vec3 &p, int label, double th) const {
+        const int kx = (int)(p.x / voxel_size_), ky = (int)(p.y / voxel_size_), kz = (int)(p.z / voxel_size_);
+        for (int i = kx - 1; i <= kx + 1; ++i)
+            for (int j = ky - 1; j <= ky + 1; ++j)
+                for (int k = kz - 1; k <= kz + 1; ++k) {
+                    const int64_t f = hash.find(Key3{i, j, k});
+                    if (f < 0) continue;
+                    for (int idx : hash.value_at(f)) {
+                        if (idx < 0 || idx >= (int)instance_in_localmap.size()) continue;
+                        if (instance_in_localmap[(size_t)idx].label != label) continue;
+                        if (norm(p - instance_in_localmap[(size_t)idx].pose) < th) return true;
+                    }
+                }
+        return false;
+    }
+    // GraphMap.cpp:149-222.  new_instance: frame node ids that became new map instances (Graph::new_instance)
+    void Update(const Graph &graph, const std::vector<InsMatch> &matches, const SE3 &pose, std::vector<int> *new_instance) {
+        RobinMap<std::vector<int>> hash;  // built once, from the instances present BEFORE this update (as the reference)
+        for (int idx = 0; idx < (int)instance_in_localmap.size(); ++idx) {
+            const Vec3 &p = instance_in_localmap[(size_t)idx].pose;
+            const Key3 k{(int)(p.x / voxel_size_), (int)(p.y / voxel_size_), (int)(p.z / voxel_size_)};
+            const int64_t f = hash.find(k);
+            if (f >= 0) hash.value_at(f).push_back(idx);
+            else hash.insert(k, std::vector<int>{idx});
+        }
+        for (const InsMatch &m : matches) {
+            bool matched = m.flag;
+            const int label = graph.node_labels[(size_t)m.frame_id];
+            const double th = label == 1 ? nn_vehicle_ : nn_pole_;
+            if (matched) {
+                const Vec3 pose_ins = pose * graph.node_centers[(size_t)m.frame_id];
+                InsNode &ins = instance_in_localmap[(size_t)m.map_id];
+                if (norm(pose_ins - ins.pose) < th) {
+                    ins.pose = (ins.pose + pose_ins) / 2.0;
+                    ins.dimension = (ins.dimension + graph.node_dimensions[(size_t)m.frame_id]) / 2.0;
+                } else {
+                    matched = false;
+                }
+            }
+            if (!matched) {
+                const Vec3 &dim = graph.node_dimensions[(size_t)m.frame_id];
+                if (label == 1) {
+                    if (graph.points_num[(size_t)m.frame_id] < 50) continue;
+                    if (dim.x < 1 || dim.y < 1 || dim.z < 1) continue;
+                } else if (label == 2 || label == 3) {
+                    if (dim.z < 1) continue;
+                }
+                InsNode ins;
+                ins.pose = pose * graph.node_centers[(size_t)m.frame_id];
+                ins.label = label;
+                ins.dimension = dim;
+                ins.points_num = graph.points_num[(size_t)m.frame_id];
+                ins.id = instance_id_++;
+                if (IsExistNearestNeighbor(hash, ins.pose, ins.label, nn_pole_)) continue;
+                if (new_instance) new_instance->push_back(m.frame_id);
+                instance_in_localmap.push_back(ins);
+            }
+        }
+        const double max_d2 = max_distance_ * max_distance_;
+        std::vector<InsNode> kept;
+        for (const InsNode &ins : instance_in_localmap)
+            if (!(sqnorm(ins.pose - pose.t) > max_d2)) kept.push_back(ins);
+        instance_in_localmap.swap(kept);
+        // ReBuildGraph (SemGraph.cpp:113-208) is BuildGraph on the instances
+        std::vector<Bbox> boxes;
+        for (const InsNode &ins : instance_in_localmap) {
+            Bbox b;
+            b.center = ins.pose; b.dimension = ins.dimension; b.label = ins.label; b.points_num = ins.points_num;
+            boxes.push_back(b);
+        }
+        InsGraphMap = build_graph(boxes, edge_dis_th_, subinterval_, graph_node_dimension_, subgraph_edge_th_);
+    }
+    // GraphMap.cpp:118-144
+    std::pair<SE3, bool> Relocalization(const Graph &graph, const std::vector<InsMatch> &matches, double inlier_rate_th, uint32_t seed,
+                                        double *score_out = nullptr) const {
+        std::vector<Vec3> m1, m2;
+        for (const InsMatch &m : matches)
+            if (m.flag) {
+                m1.push_back(graph.node_centers[(size_t)m.frame_id]);
+                m2.push_back(InsGraphMap.node_centers[(size_t)m.map_id]);
+            }
+        SE3 T;
+        bool ok = false;
+        double score = 0;
+        if (m1.size() > 3) {
+            int best = 0;
+            const auto r = ransac_alignment(m1, m2, graph.node_centers, InsGraphMap.node_centers, 500, seed, &best);
+            score = r.second;
+            if (score > inlier_rate_th) ok = true;
+            T.q = quat_from_matrix(r.first.R);
+            T.t = r.first.t;
+        }
+        if (score_out) *score_out = score;
+        return {T, ok};
+    }
+};
+
 // ---- pipeline/SemGraphSLAM.{hpp,cpp} ----------------------------------------------------------
 struct Config {  // SemGraphSLAM.hpp:25-64
     double voxel_size = 1.0, voxel_size_cluster = 0.2, max_range = 100.0, min_range = 5.0;
@@ -856,8 +1208,10 @@ struct Config {  // SemGraphSLAM.hpp:25-64
     int subinterval = 30, graph_node_dimension = 30;
     double nn_vehicle = 1.0, nn_pole = 1.0, max_local_graph_map_range = 60.0;
     int order_mode = 0, prune_mode = 0;
+    uint32_t reloc_seed = 20251031u;  // stands in for std::random_device in RansacAlignment
 };
 struct ScanOutput {
+    bool relocalized = false;
     Cloud cluster_cloud, frame_downsample, source, cropped;
     std::vector<Bbox> boxes;
     Graph graph;
@@ -870,11 +1224,15 @@ struct SemGraphSLAM {
     Config cfg;
     std::vector<SE3> poses_;
     VoxelHashMap local_map_;
+    GraphMap local_graph_map_;
     AdaptiveThreshold adaptive_threshold_;
     bool do_graph = true;
+    int relocalizations = 0, relocalization_attempts = 0;
     explicit SemGraphSLAM(const Config &c)
         : cfg(c),
           local_map_(c.voxel_size, c.max_range, c.max_points_per_voxel),
+          local_graph_map_(c.edge_dis_th, c.subgraph_edge_th, c.subinterval, c.graph_node_dimension, c.nn_vehicle, c.nn_pole,
+                           c.max_local_graph_map_range),
           adaptive_threshold_(c.initial_threshold, c.min_motion_th, c.max_range) {
         local_map_.prune_mode_ = c.prune_mode;
     }
@@ -898,8 +1256,8 @@ struct SemGraphSLAM {
         return out;
     }
     static double now_ms() { return omp_get_wtime() * 1e3; }
-    // :16-121 mainProcess (GraphMap::FindInsMatch/Update and the relocalization branch are
-    // SURVEY.md row f1 "next"; they do not influence the pose when relocalization_enable=false)
+    // :16-121 mainProcess.  GraphMap::FindInsMatch / Update and the relocalization branch (:54, :81-107, :116) run
+    // when relocalization_enable is set; they cannot influence the pose otherwise and are skipped then.
     ScanOutput mainProcess(const std::vector<Vec3> &frame, const std::vector<int> &frame_label,
                            const std::vector<double> &timestamps, bool is_kitti) {
         ScanOutput o;
@@ -934,12 +1292,31 @@ struct SemGraphSLAM {
         const SE3 initial_guess = last_pose * prediction;
         const std::vector<P4> source_4d = Fuse(o.source);
         const std::vector<P4> frame_ds_4d = Fuse(o.frame_downsample);
-        const SE3 new_pose = register_frame_semantic(source_4d, local_map_, initial_guess, 3.0 * sigma, sigma / 3.0, &o.icp);
+        const bool track = cfg.relocalization_enable && do_graph;
+        std::vector<InsMatch> frame2map;
+        if (track) frame2map = local_graph_map_.FindInsMatch(o.graph);  // :54
+        SE3 new_pose = register_frame_semantic(source_4d, local_map_, initial_guess, 3.0 * sigma, sigma / 3.0, &o.icp);
         double t5 = now_ms();
         o.stage_ms[4] = t5 - t4;
-        const SE3 model_deviation = inverse(initial_guess) * new_pose;
+        SE3 model_deviation = inverse(initial_guess) * new_pose;
+        if (track && poses_.size() > 2) {  // :83-107
+            double theta = 0;
+            so3_log(model_deviation.q, &theta);
+            if (norm(model_deviation.t) > cfg.model_deviation_trans || std::abs(theta) > cfg.model_deviation_rot) {
+                relocalization_attempts++;
+                const auto rel = local_graph_map_.Relocalization(o.graph, frame2map, cfg.inlier_rate_th, cfg.reloc_seed + (uint32_t)poses_.size());
+                if (rel.second) {
+                    IcpInfo again;
+                    new_pose = register_frame_semantic(source_4d, local_map_, rel.first, 3.0 * sigma, sigma / 3.0, &again);
+                    model_deviation = SE3();
+                    relocalizations++;
+                    o.relocalized = true;
+                }
+            }
+        }
         adaptive_threshold_.UpdateModelDeviation(model_deviation);
         local_map_.Update(frame_ds_4d, new_pose);
+        if (track) local_graph_map_.Update(o.graph, frame2map, new_pose, nullptr);  // :116
         poses_.push_back(new_pose);
         o.stage_ms[5] = now_ms() - t5;
         o.pose = new_pose;
