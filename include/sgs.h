@@ -87,7 +87,7 @@ typedef struct sgs_scan_result {
     int32_t n_raw, n_in, n_cluster, n_ds, n_src; /* cloud sizes after each stage */
     int32_t n_boxes;        /* instance nodes found (0 when enable_graph == 0) */
     int32_t map_voxels;     /* live voxels after the update (async_map_update: before it) */
-    int32_t reserved;
+    int32_t relocalized;    /* 1 when this scan was re-registered from a graph-matched pose (relocalization_enable) */
     int64_t icp_correspondences; /* summed over iterations */
     int64_t icp_candidates;      /* candidate map points examined, summed over iterations */
 } sgs_scan_result;
@@ -107,6 +107,7 @@ typedef struct sgs_stats {
     int64_t map_rehashes;
     double stage_ms[8]; /* summed HIP-event ms: 0 preprocess, 1 downsample, 2 icp, 3 map update, 4 cluster+graph */
     int64_t icp_fallbacks;         /* registrations repeated with one launch per iteration (one-launch loop gave up) */
+    int64_t relocalization_attempts, relocalizations; /* model deviation over the limit / graph-matched pose accepted */
 } sgs_stats;
 
 /* ---- lifecycle ---- */
@@ -165,6 +166,37 @@ int sgs_build_linear_system(sgs_ctx *ctx, const double *xyzl_world, int n, doubl
 int sgs_register_frame(sgs_ctx *ctx, const double *xyzl, int n, const double *initial_guess7,
                        double max_correspondence_distance, double kernel, double *out_pose7,
                        int *iterations);
+
+/* ---- local graph map: instance tracking and relocalization (frontend/GraphMap.hpp:28-71, GraphMap.cpp:88-262,
+ * core/CommonUtils.cpp:115-204,264-316).  With cfg.relocalization_enable (and enable_graph) sgs_process_scan* does per
+ * scan what SemGraphSLAM::mainProcess does (SemGraphSLAM.cpp:54,81-107,116): match the frame's instance nodes to the
+ * map's (5-NN on node descriptors + label + sub-triangle check), after the registration test the model deviation
+ * against model_deviation_trans / model_deviation_rot and, if it is too large, estimate the pose from the matched
+ * nodes (500 RANSAC triplets + SVD, accepted when the inlier rate exceeds inlier_rate_th) and register again from
+ * there; then fold the frame's nodes into the map (averaging matched ones, adding new ones unless one of the same
+ * class is near, dropping those beyond max_local_graph_map_range) and rebuild the map's graph.  This mode is strictly
+ * serial (no prefetch, no asynchronous map update).  The reference seeds its RANSAC from std::random_device; here
+ * the sequence is fixed (seed + scan index), so runs are reproducible.  The pieces, for hosts that keep their own
+ * pipeline:
+ *   track       = BuildGraph(boxes) -> FindInsMatch -> Update(pose); matches: nb rows [flag, frame id, map id],
+ *                 new_instance: frame ids that became map instances
+ *   instances   : rows of 9 doubles: label, id, position xyz, dimension xyz, points
+ *   relocalize  = BuildGraph(boxes) -> FindInsMatch -> Relocalization; *ok = accepted ---- */
+int sgs_graph_map_clear(sgs_ctx *ctx);
+int sgs_graph_map_track(sgs_ctx *ctx, const double *boxes, int nb, const double *pose7, int32_t *matches, int32_t *new_instance, int *n_new);
+int sgs_graph_map_instances(sgs_ctx *ctx, double *out9, int cap, int *n);
+int sgs_graph_map_relocalize(sgs_ctx *ctx, const double *boxes, int nb, double inlier_rate_th, uint32_t seed, double *out_pose7,
+                             double *score, int *n_matched, int *ok);
+/* FindInsMatch (GraphMap.cpp:43-113) on graphs given as arrays: boxes n x 8, node descriptors n x desc_dim, sub-triangle
+ * counts per node and the triangles (3 sorted edge lengths each, node after node) as sgs_build_graph returns them.
+ * matches: nf rows [flag, frame id, map id]. */
+int sgs_find_ins_match(const double *frame_boxes, int nf, const float *frame_desc, const int32_t *frame_tri_counts, const double *frame_tri,
+                       const double *map_boxes, int nm, const float *map_desc, const int32_t *map_tri_counts, const double *map_tri,
+                       int desc_dim, int32_t *matches);
+/* SolveSVD (CommonUtils.cpp:264-316): R (row-major 3x3), t with R p1 + t ~ p2.  RansacAlignment (:115-204), seeded. */
+int sgs_solve_svd(const double *p1, const double *p2, int n, double *R9, double *t3);
+int sgs_ransac_alignment(const double *match1, const double *match2, int n_match, const double *nodes1, int n1, const double *nodes2, int n2,
+                         int max_iter, uint32_t seed, double *R9, double *t3, double *score, int *best_inlier);
 
 /* ---- scan descriptor for the back-end: GenScanDescriptors (loopclosure/LoopClosure.cpp:15-32) = GenGraphDescriptors
  * (:93-140: six label-pair histograms of edge length + three instance counts) followed by GenBackDescriptors

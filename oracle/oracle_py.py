@@ -92,6 +92,7 @@ def lib():
         L.sgo_graphmap_track.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
         L.sgo_graphmap_instances.argtypes = [c_vp, c_vp, c_int]
         L.sgo_graphmap_relocalize.argtypes = [c_vp, c_vp, c_int, c_dbl, ctypes.c_uint32, c_vp, c_vp, c_vp]
+        L.sgo_find_ins_match.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp]
         L.sgo_solve_svd.restype = None
         L.sgo_solve_svd.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp]
         L.sgo_ransac_alignment.argtypes = [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, ctypes.c_uint32, c_vp, c_vp, c_vp]
@@ -306,6 +307,18 @@ def fast_icp(xyzl_a, xyzl_b, init7, voxel_size_map=1.0, max_points_per_voxel=5, 
     lib().sgo_fast_icp(a.ctypes.data, len(a), b.ctypes.data, len(b), g.ctypes.data, float(voxel_size_map),
                        int(max_points_per_voxel), float(max_corr), out.ctypes.data, info.ctypes.data)
     return out, dict(iterations=int(info[0]), candidates=int(info[1]), correspondences=int(info[2]))
+
+
+def find_ins_match(frame, gmap):
+    """GraphMap.cpp:88-113 on two graphs given as dicts with boxes, desc, tri_counts, triangles."""
+    def arrs(g):
+        return (_f64(g["boxes"]).reshape(-1, 8), np.ascontiguousarray(g["desc"], dtype=np.float32), _i32(g["tri_counts"]),
+                _f64(g["triangles"]).reshape(-1, 3))
+    fb, fd, fc, ft = arrs(frame); mb, md, mc, mt = arrs(gmap)
+    out = np.zeros((max(len(fb), 1), 3), dtype=np.int32)
+    n = lib().sgo_find_ins_match(fb.ctypes.data, len(fb), fd.ctypes.data, fc.ctypes.data, ft.ctypes.data, mb.ctypes.data, len(mb),
+                                 md.ctypes.data, mc.ctypes.data, mt.ctypes.data, fd.shape[1] if fd.ndim == 2 else 1, out.ctypes.data)
+    return out[:n].copy()
 
 
 def solve_svd(p1, p2):

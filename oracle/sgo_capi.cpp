@@ -400,6 +400,29 @@ int sgo_graphmap_relocalize(void *hh, const double *boxes, int nb, double inlier
     pose_out(r.first, pose7);
     return r.second ? 1 : 0;
 }
+// FindInsMatch on graphs given as arrays (the descriptors are inputs, so two implementations can be compared on equal ones)
+static Graph graph_from_arrays(const double *boxes, int n, const float *desc, const int32_t *tc, const double *tri, int D) {
+    Graph g;
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        g.node_labels.push_back((int)boxes[8 * i + 6]);
+        g.node_centers.push_back(Vec3(boxes[8 * i], boxes[8 * i + 1], boxes[8 * i + 2]));
+        g.node_desc.emplace_back(desc + (size_t)i * D, desc + (size_t)(i + 1) * D);
+        g.node_sub_triangles.emplace_back();
+        for (int k = 0; k < tc[i]; ++k, ++off) g.node_sub_triangles.back().push_back(Vec3(tri[3 * off], tri[3 * off + 1], tri[3 * off + 2]));
+    }
+    return g;
+}
+int sgo_find_ins_match(const double *fb, int nf, const float *fd, const int32_t *fc, const double *ft, const double *mb, int nm, const float *md,
+                       const int32_t *mc, const double *mt, int D, int32_t *matches) {
+    GraphMap gm(60, 20, 30, 30, 1, 1, 100);
+    gm.InsGraphMap = graph_from_arrays(mb, nm, md, mc, mt, D);
+    const std::vector<InsMatch> m = gm.FindInsMatch(graph_from_arrays(fb, nf, fd, fc, ft, D));
+    for (size_t i = 0; i < m.size(); ++i) {
+        matches[3 * i] = m[i].flag ? 1 : 0; matches[3 * i + 1] = m[i].frame_id; matches[3 * i + 2] = m[i].map_id;
+    }
+    return (int)m.size();
+}
 void sgo_solve_svd(const double *p1, const double *p2, int n, double *R9, double *t3) {
     const Iso3 T = solve_svd(vec3_in(p1, n), vec3_in(p2, n));
     for (int i = 0; i < 3; ++i)

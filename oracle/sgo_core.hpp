@@ -904,42 +904,11 @@ inline std::vector<std::pair<int, int>> find_correspondences_knn(const Graph &fr
     }
     return out;
 }
-// CommonUtils.cpp:264-316 SolveSVD: Kabsch on the centred pairs, R = V E U^T.  The 3x3 SVD is taken from the
-// eigen-decomposition of W^T W (cyclic Jacobi); a rank-deficient W (three points are always coplanar after
+// CommonUtils.cpp:264-316 SolveSVD: Kabsch on the centred pairs, R = V E U^T.  The 3x3 SVD is a one-sided (Hestenes)
+// Jacobi iteration on W; a rank-deficient W (three points are always coplanar after
 // centring) has its missing directions completed by cross products - the determinant rule then fixes the sign,
 // so every completion gives the same R.  Fewer than two independent directions (repeated sample indices) has no
 // defined answer in the reference either (whatever JacobiSVD leaves); here it returns R = I.
-inline void jacobi3(double A[3][3], double V[3][3], double w[3]) {
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        if (off < 1e-300) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (A[p][q] == 0.0) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::abs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < 3; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - sn * akq;
-                    A[k][q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - sn * aqk;
-                    A[q][k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + c * vkq;
-                }
-            }
-    }
-    for (int i = 0; i < 3; ++i) w[i] = A[i][i];
-}
 struct Iso3 {  // Eigen::Isometry3d as rotation matrix + translation
     Mat3 R;
     Vec3 t;
@@ -956,26 +925,53 @@ inline Iso3 solve_svd(const std::vector<Vec3> &n1, const std::vector<Vec3> &n2) 
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) W[r][c] += av[r] * bv[c];
     }
-    double WtW[3][3], V[3][3], ev[3];
+    // one-sided (Hestenes) Jacobi SVD of W: rotate column pairs of A = W V until they are orthogonal; then the
+    // column norms are the singular values, the normalised columns U, and V the accumulated rotations
+    double A[3][3], V[3][3];
     for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) WtW[r][c] = W[0][r] * W[0][c] + W[1][r] * W[1][c] + W[2][r] * W[2][c];
-    jacobi3(WtW, V, ev);
+        for (int c = 0; c < 3; ++c) {
+            A[r][c] = W[r][c];
+            V[r][c] = r == c ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 3; ++k) {
+                    alpha += A[k][p] * A[k][p];
+                    beta += A[k][q] * A[k][q];
+                    gamma += A[k][p] * A[k][q];
+                }
+                if (gamma == 0.0 || std::abs(gamma) <= 1e-16 * std::sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::abs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sv[3];
+    for (int j = 0; j < 3; ++j) sv[j] = std::sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
     int ord[3] = {0, 1, 2};
-    std::sort(ord, ord + 3, [&](int a, int b) { return ev[a] > ev[b]; });
+    std::sort(ord, ord + 3, [&](int a, int b) { return sv[a] > sv[b]; });
     Vec3 v[3], u[3];
     for (int k = 0; k < 3; ++k) v[k] = Vec3(V[0][ord[k]], V[1][ord[k]], V[2][ord[k]]);
-    const double smax = std::sqrt(std::max(ev[ord[0]], 0.0));
+    const double smax = sv[ord[0]];
     int rank = 0;
     for (int k = 0; k < 3; ++k) {
-        const double sv = std::sqrt(std::max(ev[ord[k]], 0.0));
-        if (sv > 1e-9 * smax && sv > 1e-150) {
-            const Vec3 wv(W[0][0] * v[k].x + W[0][1] * v[k].y + W[0][2] * v[k].z, W[1][0] * v[k].x + W[1][1] * v[k].y + W[1][2] * v[k].z,
-                          W[2][0] * v[k].x + W[2][1] * v[k].y + W[2][2] * v[k].z);
-            u[k] = wv / sv;
-            rank = k + 1;
-        } else {
-            break;
-        }
+        const double sk = sv[ord[k]];
+        if (!(sk > 1e-9 * smax && sk > 1e-150)) break;
+        u[k] = Vec3(A[0][ord[k]] / sk, A[1][ord[k]] / sk, A[2][ord[k]] / sk);
+        rank = k + 1;
     }
     Iso3 T;
     if (rank < 2) {

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sgs_reset_stats", "sgs_set_profiling", "sgs_preprocess", "sgs_correct_kitti", "sgs_deskew",
     "sgs_voxel_keys", "sgs_voxel_downsample", "sgs_map_clear", "sgs_map_empty", "sgs_map_add_points",
     "sgs_map_update", "sgs_map_prune", "sgs_map_size", "sgs_map_pointcloud", "sgs_map_dump",
-    "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_shard_set", "sgs_fast_icp", "sgs_scan_descriptor", "sgs_gen_scan_descriptor", "sgs_cluster_points",
+    "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_shard_set", "sgs_fast_icp", "sgs_graph_map_clear", "sgs_graph_map_track", "sgs_graph_map_instances", "sgs_graph_map_relocalize", "sgs_find_ins_match", "sgs_solve_svd", "sgs_ransac_alignment", "sgs_scan_descriptor", "sgs_gen_scan_descriptor", "sgs_cluster_points",
     "sgs_build_graph", "sgs_process_scan", "sgs_process_scan_f32", "sgs_process_scan_f32_dev", "sgs_prefetch_scan_f32_dev", "sgs_get_cloud",
     "sgs_get_boxes", "sgs_get_poses", "sgs_remap_labels",
 ]
@@ -59,7 +59,7 @@ class SgsScanResult(ctypes.Structure):
         ("size", u32), ("icp_iterations", i32),
         ("pose", c_dbl * 7), ("initial_guess", c_dbl * 7), ("sigma", c_dbl),
         ("n_raw", i32), ("n_in", i32), ("n_cluster", i32), ("n_ds", i32), ("n_src", i32),
-        ("n_boxes", i32), ("map_voxels", i32), ("reserved", i32),
+        ("n_boxes", i32), ("map_voxels", i32), ("relocalized", i32),
         ("icp_correspondences", i64), ("icp_candidates", i64),
     ]
 
@@ -69,7 +69,7 @@ class SgsStats(ctypes.Structure):
         ("size", u32), ("reserved", u32), ("scans", i64), ("icp_kernel_launches", i64),
         ("icp_kernel_ms_total", c_dbl), ("icp_queries_total", i64), ("icp_candidates_total", i64),
         ("icp_probes_total", i64), ("map_insert_cas_retries", i64), ("map_rehashes", i64),
-        ("stage_ms", c_dbl * 8), ("icp_fallbacks", i64),
+        ("stage_ms", c_dbl * 8), ("icp_fallbacks", i64), ("relocalization_attempts", i64), ("relocalizations", i64),
     ]
 
 
@@ -116,6 +116,13 @@ def lib():
         L.sgs_map_get_correspondences.argtypes = [c_vp, c_vp, c_int, c_dbl, c_vp, c_vp, c_vp, c_int, c_vp]
         L.sgs_build_linear_system.argtypes = [c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]
         L.sgs_register_frame.argtypes = [c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, c_vp, c_vp]
+        L.sgs_graph_map_clear.argtypes = [c_vp]
+        L.sgs_graph_map_track.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
+        L.sgs_graph_map_instances.argtypes = [c_vp, c_vp, c_int, c_vp]
+        L.sgs_graph_map_relocalize.argtypes = [c_vp, c_vp, c_int, c_dbl, u32, c_vp, c_vp, c_vp, c_vp]
+        L.sgs_find_ins_match.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp]
+        L.sgs_solve_svd.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp]
+        L.sgs_ransac_alignment.argtypes = [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, u32, c_vp, c_vp, c_vp, c_vp]
         L.sgs_scan_descriptor.argtypes = [c_vp, c_vp, c_int, c_vp]
         L.sgs_gen_scan_descriptor.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_dbl, c_int, c_vp, c_int, c_vp]
         L.sgs_fast_icp.argtypes = [c_vp, c_vp, c_int, c_vp, c_int, c_vp, ctypes.c_float, c_int, c_dbl, c_vp, c_vp]
@@ -159,6 +166,39 @@ def _f64(a):
 
 def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def find_ins_match(frame, gmap):
+    """GraphMap.cpp:88-113 on two graphs given as dicts with boxes, desc, tri_counts, triangles (BuildGraph's outputs)."""
+    def arrs(g):
+        return (_f64(g["boxes"]).reshape(-1, 8), np.ascontiguousarray(g["desc"], dtype=np.float32), _i32(g["tri_counts"]),
+                _f64(g["triangles"]).reshape(-1, 3))
+    fb, fd, fc, ft = arrs(frame); mb, md, mc, mt = arrs(gmap)
+    out = np.zeros((max(len(fb), 1), 3), dtype=np.int32)
+    r = lib().sgs_find_ins_match(fb.ctypes.data, len(fb), fd.ctypes.data, fc.ctypes.data, ft.ctypes.data, mb.ctypes.data, len(mb),
+                                 md.ctypes.data, mc.ctypes.data, mt.ctypes.data, fd.shape[1] if fd.ndim == 2 else 1, out.ctypes.data)
+    if r != SGS_OK:
+        raise SgsError(r, "sgs_find_ins_match")
+    return out[:len(fb)].copy()
+
+
+def solve_svd(p1, p2):
+    """core/CommonUtils.cpp:264-316 -> (R, t) with R @ p1 + t ~ p2."""
+    a = _f64(p1); b = _f64(p2); R = np.empty((3, 3)); t = np.empty(3)
+    r = lib().sgs_solve_svd(a.ctypes.data, b.ctypes.data, len(a), R.ctypes.data, t.ctypes.data)
+    if r != SGS_OK:
+        raise SgsError(r, "sgs_solve_svd")
+    return R, t
+
+
+def ransac_alignment(m1, m2, nodes1, nodes2, max_iter=500, seed=1):
+    """core/CommonUtils.cpp:115-204, seeded -> (R, t, score, best_inlier)."""
+    a = _f64(m1); b = _f64(m2); n1 = _f64(nodes1); n2 = _f64(nodes2); R = np.empty((3, 3)); t = np.empty(3); sc = c_dbl(); best = c_int()
+    r = lib().sgs_ransac_alignment(a.ctypes.data, b.ctypes.data, len(a), n1.ctypes.data, len(n1), n2.ctypes.data, len(n2), int(max_iter),
+                                   int(seed), R.ctypes.data, t.ctypes.data, ctypes.byref(sc), ctypes.byref(best))
+    if r != SGS_OK:
+        raise SgsError(r, "sgs_ransac_alignment")
+    return R, t, sc.value, best.value
 
 
 def remap_labels(raw):
@@ -302,6 +342,30 @@ class Context:
                                           float(kernel), out.ctypes.data, ctypes.byref(it)))
         return out, it.value
 
+    # ---- GraphMap: instance tracking and relocalization (frontend/GraphMap.cpp) ----
+    def GraphMapClear(self):
+        self._ck(lib().sgs_graph_map_clear(self.h))
+
+    def GraphMapTrack(self, boxes, pose7):
+        """BuildGraph -> FindInsMatch -> Update; -> (matches (nb, 3) [flag, frame id, map id], new_instance ids)."""
+        b = _f64(boxes).reshape(-1, 8); p = _f64(pose7); nb = len(b)
+        m = np.zeros((max(nb, 1), 3), dtype=np.int32); fresh = np.zeros(max(nb, 1), dtype=np.int32); nn = c_int()
+        self._ck(lib().sgs_graph_map_track(self.h, b.ctypes.data, nb, p.ctypes.data, m.ctypes.data, fresh.ctypes.data, ctypes.byref(nn)))
+        return m[:nb].copy(), fresh[:nn.value].copy()
+
+    def GraphMapInstances(self):
+        n = c_int()
+        self._ck(lib().sgs_graph_map_instances(self.h, None, 0, ctypes.byref(n)))
+        out = np.empty((max(n.value, 1), 9))
+        self._ck(lib().sgs_graph_map_instances(self.h, out.ctypes.data, n.value, ctypes.byref(n)))
+        return out[:n.value].copy()
+
+    def Relocalization(self, boxes, inlier_rate_th=0.4, seed=1):
+        b = _f64(boxes).reshape(-1, 8); pose = np.empty(7); sc = c_dbl(); nm = c_int(); ok = c_int()
+        self._ck(lib().sgs_graph_map_relocalize(self.h, b.ctypes.data, len(b), float(inlier_rate_th), int(seed), pose.ctypes.data,
+                                                ctypes.byref(sc), ctypes.byref(nm), ctypes.byref(ok)))
+        return bool(ok.value), pose, sc.value, nm.value
+
     # ---- GenScanDescriptors (loopclosure/LoopClosure.cpp:15-32) ----
     def GenScanDescriptors(self, boxes, xyz, label, edge_dis_th=60.0, subinterval=30):
         boxes = _f64(boxes).reshape(-1, 8); xyz = _f64(xyz); lab = _i32(label)
@@ -375,7 +439,7 @@ class Context:
     def _result(res):
         return dict(pose=np.array(res.pose[:]), initial_guess=np.array(res.initial_guess[:]), sigma=res.sigma,
                     iterations=res.icp_iterations, n_raw=res.n_raw, n_in=res.n_in, n_cluster=res.n_cluster,
-                    n_ds=res.n_ds, n_src=res.n_src, n_boxes=res.n_boxes, map_voxels=res.map_voxels,
+                    n_ds=res.n_ds, n_src=res.n_src, n_boxes=res.n_boxes, map_voxels=res.map_voxels, relocalized=bool(res.relocalized),
                     correspondences=res.icp_correspondences, candidates=res.icp_candidates)
 
     def mainProcess(self, frame, frame_label, timestamps=None, dataset=""):

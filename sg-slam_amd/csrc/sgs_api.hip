@@ -21,6 +21,7 @@
 
 #include "sgs.h"
 #include "sgs_device.h"
+#include "graph_map.h"
 #include "sgs_graph.h"
 
 using namespace sgs;
@@ -185,6 +186,10 @@ struct sgs_ctx {
     DevState *st = nullptr;
     DevState *st_host = nullptr;  // pinned
     uint32_t *back_bitmap = nullptr;  // scan descriptor: occupancy bitmaps (kBackBitmapWords), allocated at first use
+    // local map of tracked instances + relocalization (cfg.relocalization_enable; graph_map.h)
+    GraphMapState gmap;
+    GraphMapParams gmp;
+    uint32_t reloc_seed = 20251031u;  // stands in for std::random_device (CommonUtils.cpp:119); + scan index per attempt
     // second map + state of the loop-pair refinement (sgs_fast_icp), allocated at its first call
     MapBuf loop_map;
     DevState *st_loop = nullptr;
@@ -749,6 +754,32 @@ void discard_prefetch(sgs_ctx *c) {
     discard_prefetch(c, c->sets[1]);
 }
 
+// BuildGraph / ReBuildGraph of `boxes` into what GraphMap needs, through the device-assisted builder (second stream;
+// the helper threads are idle whenever this is called)
+int build_graph_data(sgs_ctx *c, const double *boxes, int nb, GraphData *out) {
+    const sgs_config &cfg = c->cfg;
+    out->n = nb;
+    out->D = 3 * cfg.subinterval + cfg.graph_node_dimension;
+    out->boxes.assign(boxes, boxes + 8 * (size_t)nb);
+    out->desc.assign((size_t)nb * out->D, 0.f);
+    out->tri_counts.assign((size_t)nb, 0);
+    size_t cap = (size_t)nb * (size_t)std::max(nb - 1, 0) * (size_t)std::max(nb - 2, 0) / 2;
+    cap = std::min<size_t>(std::max<size_t>(cap, 1), (size_t)4 << 20);
+    out->tri.assign(3 * cap, 0.0);
+    int ne = 0, nt = 0;
+    std::string err;
+    const int r = graph_build(c->stream2, c->gs, boxes, nb, cfg.edge_dis_th, cfg.subinterval, cfg.graph_node_dimension, cfg.subgraph_edge_th,
+                              out->desc.data(), nullptr, nullptr, nullptr, nullptr, nullptr, 0, &ne, out->tri_counts.data(), out->tri.data(),
+                              (int)cap, &nt, nullptr, &err);
+    if (r) return fail(c, r, "graph map: %s", err.c_str());
+    out->tri.resize(3 * (size_t)nt);
+    out->index_triangles();
+    return SGS_OK;
+}
+GraphBuilder graph_builder(sgs_ctx *c) {
+    return [c](const double *boxes, int nb, GraphData *out) { return build_graph_data(c, boxes, nb, out); };
+}
+
 int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const int32_t *d_label, int n,
                      const double *d_ts, int is_kitti, sgs_scan_result *res) {
     if (n < 0 || n > c->N) return fail(c, SGS_ECAPACITY, "scan of %d points exceeds max_points=%d", n, c->N);
@@ -820,7 +851,8 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     // up (its inter-block wait ran out) the queued update skips itself and both are repeated the slow way.
     int iters = 0, r;
     const double t_icp0 = now_ms();
-    const bool ahead = cfg.async_map_update != 0 && !c->profiling && c->shard_world == 1 && c->icp_persistent && c->map_live_host != 0;
+    const bool track = cfg.relocalization_enable != 0 && cfg.enable_graph != 0;  // instance tracking + relocalization: strictly serial
+    const bool ahead = cfg.async_map_update != 0 && !c->profiling && c->shard_world == 1 && c->icp_persistent && c->map_live_host != 0 && !track;
     auto enqueue_map_update = [&](bool guarded) -> int {
         // sizing by the last census the host has seen plus everything that may have been added since
         int rr = maybe_rehash(c, guarded ? n + c->last_n[3] : n);
@@ -851,7 +883,7 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
         if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[3], s);
     }
     const double t_icp_done = now_ms();
-    const bool async = ahead || (cfg.async_map_update != 0 && iters > 0 && !c->profiling && c->shard_world == 1);
+    const bool async = ahead || (cfg.async_map_update != 0 && iters > 0 && !c->profiling && c->shard_world == 1 && !track);
     DevState hs;  // host view of the device state for this scan
     if (async) {
         const HostMirror &mi = *c->mirror;
@@ -873,6 +905,35 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
         hs.icp_corr = mi.icp_corr; hs.icp_cand = mi.icp_cand; hs.icp_probe = mi.icp_probe;
         hs.map_live = mi.icp_map_live;  // voxels of the map this scan was registered against
     }
+    // ---- instance tracking and relocalization (P/SemGraphSLAM.cpp:54,81-107): needs the frame graph and the pose
+    // before the map is touched
+    GraphData frame_graph;
+    std::vector<InsMatch> frame2map;
+    bool relocalized = false;
+    Rigid pose_after_icp = rigid_identity();
+    if (track) {
+        if ((r = sync_state(c))) return r;
+        pose_after_icp = c->st_host->T_total;
+        wait_set_job(S);
+        if (S.graph_rc) {
+            c->err = S.gerr;
+            return S.graph_rc;
+        }
+        if ((r = build_graph_data(c, S.boxes.data(), (int)(S.boxes.size() / 8), &frame_graph))) return r;
+        frame2map = find_ins_match(frame_graph, c->gmap.graph);
+        const Rigid dev = compose(invert(guess), pose_after_icp);
+        if (c->poses.size() > 2 && (sqrt(sq3(dev.t)) > cfg.model_deviation_trans || rigid_rotation_angle(dev) > cfg.model_deviation_rot)) {
+            c->stats.relocalization_attempts++;
+            Rigid reloc;
+            if (graph_map_relocalize(c->gmap, frame_graph, frame2map, cfg.inlier_rate_th, c->reloc_seed + (uint32_t)c->poses.size(), &reloc,
+                                     nullptr, nullptr)) {
+                int again = 0;
+                if ((r = run_icp(c, S.src, S.sizes + 3, S.sizes, reloc, 3.0 * sigma, sigma / 3.0, &again))) return r;
+                relocalized = true;
+                c->stats.relocalizations++;
+            }
+        }
+    }
     if (!ahead) {
         if ((r = enqueue_map_update(false))) return r;
         if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[4], s);
@@ -889,8 +950,9 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     const DevState &h = hs;
     const Rigid new_pose = h.T_total;
     // ---- model deviation / pose list (P/SemGraphSLAM.cpp:79,110,119)
-    c->model_deviation = compose(invert(guess), new_pose);
+    c->model_deviation = relocalized ? rigid_identity() : compose(invert(guess), new_pose);  // :99
     c->poses.push_back(new_pose);
+    if (track && (r = graph_map_update(c->gmap, c->gmp, frame_graph, frame2map, new_pose, graph_builder(c), nullptr))) return r;  // :116
     // ---- chain the next scan's registration behind this scan's map update when its front half is already
     // enqueued (sgs_prefetch_scan_f32_dev): the device never waits for the host between two scans
     if (async && c->icp_persistent) {
@@ -946,6 +1008,7 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
         o.n_raw = n; o.n_in = h.n_in; o.n_cluster = h.n_c; o.n_ds = h.n_d; o.n_src = h.n_s;
         o.n_boxes = n_boxes;
         o.map_voxels = h.map_live;
+        o.relocalized = relocalized ? 1 : 0;
         o.icp_correspondences = h.icp_corr;
         o.icp_candidates = h.icp_cand;
         memcpy(res, &o, sz);
@@ -1088,6 +1151,9 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     if (hipHostMalloc((void **)&c->st_host, sizeof(DevState), hipHostMallocDefault) != hipSuccess) return bail(SGS_ENOMEM);
     if ((r = alloc_map(c, &c->map, cfg.map_capacity_log2))) return bail(r);
     if ((r = graph_scratch_alloc(c->gs, c->N))) return bail(fail(c, r, "graph scratch allocation failed"));
+    c->gmp.nn_vehicle = cfg.nearest_neighbor_vehicle_disth;
+    c->gmp.nn_pole = cfg.nearest_neighbor_pole_disth;
+    c->gmp.max_distance = cfg.max_local_graph_map_range;
     c->gworker.start(device);
     c->fworker.start(device);
     if (hipMemsetAsync(c->st, 0, sizeof(DevState), c->stream) != hipSuccess) return bail(SGS_EHIP);
@@ -1528,6 +1594,110 @@ int sgs_scan_descriptor(sgs_ctx *c, float *desc, int cap, int *n_out) {
                                 c->cfg.subinterval, desc, cap, n_out);
 }
 
+// ---- local graph map: instance tracking + relocalization (frontend/GraphMap.cpp) ----
+
+int sgs_graph_map_clear(sgs_ctx *c) {
+    ENTER(c);
+    c->gmap.clear();
+    return SGS_OK;
+}
+int sgs_graph_map_track(sgs_ctx *c, const double *boxes, int nb, const double *pose7, int32_t *matches, int32_t *new_instance, int *n_new) {
+    ENTER(c);
+    if (nb < 0 || (nb && (!boxes || !matches || !new_instance)) || !pose7) return fail(c, SGS_EINVAL, "bad argument");
+    GraphData frame;
+    int r;
+    if ((r = build_graph_data(c, boxes, nb, &frame))) return r;
+    const std::vector<InsMatch> m = find_ins_match(frame, c->gmap.graph);
+    std::vector<int> fresh;
+    if ((r = graph_map_update(c->gmap, c->gmp, frame, m, rigid_from_pose7(pose7), graph_builder(c), &fresh))) return r;
+    for (size_t i = 0; i < m.size(); ++i) {
+        matches[3 * i] = m[i].flag; matches[3 * i + 1] = m[i].frame_id; matches[3 * i + 2] = m[i].map_id;
+    }
+    for (size_t i = 0; i < fresh.size(); ++i) new_instance[i] = fresh[i];
+    if (n_new) *n_new = (int)fresh.size();
+    return SGS_OK;
+}
+int sgs_graph_map_instances(sgs_ctx *c, double *out9, int cap, int *n) {
+    ENTER(c);
+    if (!n) return fail(c, SGS_EINVAL, "null argument");
+    const int m = (int)c->gmap.inst.size();
+    *n = m;
+    for (int i = 0; i < m && i < cap && out9; ++i) {
+        const MapInstance &v = c->gmap.inst[(size_t)i];
+        double *o = out9 + 9 * (size_t)i;
+        o[0] = v.label; o[1] = v.id; o[2] = v.pose.x; o[3] = v.pose.y; o[4] = v.pose.z; o[5] = v.dim.x; o[6] = v.dim.y; o[7] = v.dim.z; o[8] = v.points;
+    }
+    return m > cap && out9 ? fail(c, SGS_ECAPACITY, "output capacity %d < %d", cap, m) : SGS_OK;
+}
+int sgs_graph_map_relocalize(sgs_ctx *c, const double *boxes, int nb, double inlier_rate_th, uint32_t seed, double *out_pose7, double *score,
+                             int *n_matched, int *ok) {
+    ENTER(c);
+    if (nb < 0 || (nb && !boxes) || !out_pose7 || !ok) return fail(c, SGS_EINVAL, "bad argument");
+    GraphData frame;
+    int r;
+    if ((r = build_graph_data(c, boxes, nb, &frame))) return r;
+    const std::vector<InsMatch> m = find_ins_match(frame, c->gmap.graph);
+    Rigid T;
+    *ok = graph_map_relocalize(c->gmap, frame, m, inlier_rate_th, seed, &T, score, n_matched) ? 1 : 0;
+    rigid_to_pose7(T, out_pose7);
+    return SGS_OK;
+}
+int sgs_find_ins_match(const double *frame_boxes, int nf, const float *frame_desc, const int32_t *frame_tri_counts, const double *frame_tri,
+                       const double *map_boxes, int nm, const float *map_desc, const int32_t *map_tri_counts, const double *map_tri,
+                       int desc_dim, int32_t *matches) {
+    if (nf < 0 || nm < 0 || desc_dim < 1 || (nf && (!frame_boxes || !frame_desc || !frame_tri_counts || !matches)) ||
+        (nm && (!map_boxes || !map_desc || !map_tri_counts)))
+        return SGS_EINVAL;
+    auto load = [desc_dim](const double *boxes, int n, const float *desc, const int32_t *tc, const double *tri) {
+        GraphData g;
+        g.n = n; g.D = desc_dim;
+        g.boxes.assign(boxes, boxes + 8 * (size_t)n);
+        g.desc.assign(desc, desc + (size_t)n * desc_dim);
+        g.tri_counts.assign(tc, tc + n);
+        g.index_triangles();
+        if (tri) g.tri.assign(tri, tri + 3 * g.tri_off[(size_t)n]);
+        else g.tri.assign(3 * g.tri_off[(size_t)n], 0.0);
+        return g;
+    };
+    const GraphData f = load(frame_boxes, nf, frame_desc, frame_tri_counts, frame_tri), m = load(map_boxes, nm, map_desc, map_tri_counts, map_tri);
+    const std::vector<InsMatch> r = find_ins_match(f, m);
+    for (size_t i = 0; i < r.size(); ++i) {
+        matches[3 * i] = r[i].flag; matches[3 * i + 1] = r[i].frame_id; matches[3 * i + 2] = r[i].map_id;
+    }
+    return SGS_OK;
+}
+int sgs_solve_svd(const double *p1, const double *p2, int n, double *R9, double *t3) {
+    if (n < 1 || !p1 || !p2 || !R9 || !t3) return SGS_EINVAL;
+    std::vector<D3> a((size_t)n), b((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        a[(size_t)i] = D3{p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]};
+        b[(size_t)i] = D3{p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]};
+    }
+    const Iso T = solve_svd(a.data(), b.data(), n);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R9[3 * i + j] = T.R.m[i][j];
+    t3[0] = T.t.x; t3[1] = T.t.y; t3[2] = T.t.z;
+    return SGS_OK;
+}
+int sgs_ransac_alignment(const double *m1, const double *m2, int nm, const double *nodes1, int n1, const double *nodes2, int n2, int max_iter,
+                         uint32_t seed, double *R9, double *t3, double *score, int *best_inlier) {
+    if (nm < 1 || n1 < 0 || n2 < 0 || !m1 || !m2 || !R9 || !t3) return SGS_EINVAL;
+    auto vec = [](const double *p, int n) {
+        std::vector<D3> v((size_t)n);
+        for (int i = 0; i < n; ++i) v[(size_t)i] = D3{p[3 * i], p[3 * i + 1], p[3 * i + 2]};
+        return v;
+    };
+    int best = 0;
+    double sc = 0;
+    const Iso T = ransac_alignment(vec(m1, nm), vec(m2, nm), vec(nodes1, n1), vec(nodes2, n2), max_iter, seed, &best, &sc);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R9[3 * i + j] = T.R.m[i][j];
+    t3[0] = T.t.x; t3[1] = T.t.y; t3[2] = T.t.z;
+    if (score) *score = sc;
+    if (best_inlier) *best_inlier = best;
+    return SGS_OK;
+}
+
 // ---- loop-pair refinement: loopclosure/FastIcp.cpp:205-220 get_trans ----
 // The same kernels with another parameterisation: a second voxel map (float-held voxel size, cap per voxel from
 // the caller, no pruning) is filled with cloud B, cloud A is registered against it with unit weights
@@ -1672,6 +1842,7 @@ int sgs_prefetch_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *
     CHECK_N(c, n);
     if (n && (!xyzi_dev || !label_dev)) return fail(c, SGS_EINVAL, "null argument");
     if (c->cfg.deskew) return SGS_OK;  // the deskew of a scan needs the pose of the one before it: nothing to run ahead
+    if (c->cfg.relocalization_enable && c->cfg.enable_graph) return SGS_OK;  // the tracked-instance map is updated scan by scan
     // the set that holds no pending hint: normally the one whose scan the caller has just finished with
     ScanSet &N = c->sets[c->cur ^ 1].prefetched ? c->sets[c->cur] : c->sets[c->cur ^ 1];
     if (N.prefetched) return SGS_OK;  // two hints already pending: ignore this one

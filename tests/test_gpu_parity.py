@@ -813,3 +813,128 @@ def test_pipeline_survives_a_one_launch_loop_that_gives_up(monkeypatch):
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
     for p in d_x + d_l:
         hip.hipFree(p)
+
+
+# ---------------- GraphMap: instance tracking + relocalization ----------------
+def _boxes_of(frame, shape="hdl64"):
+    _, xyz, lab = _scan(frame, shape)
+    px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
+    cx, cl, _, _ = O.voxel_downsample(px, pl, 0.2)
+    return O.cluster_points(cx, cl, 2.0, 0.5, 2.0)[0]
+
+
+def test_solve_svd_and_ransac_match_oracle():
+    rng = np.random.default_rng(5)
+    T = O.se3_exp([0.5, -1.0, 0.3, 0.1, -0.2, 0.4])
+    for n in (3, 4, 9):
+        P = rng.normal(size=(n, 3)) * 6
+        Q = O.se3_act(T, P) + rng.normal(size=(n, 3)) * 0.01
+        Rg, tg = api.solve_svd(P, Q)
+        Ro, to = O.solve_svd(P, Q)
+        assert np.abs(Rg - Ro).max() < 1e-12 and np.abs(tg - to).max() < 1e-12
+        assert abs(np.linalg.det(Rg) - 1) < 1e-12 and np.abs(Rg @ P.T + tg[:, None] - Q.T).max() < 0.1
+    # reflection case: the determinant rule must flip the weakest direction
+    P = np.array([[1.0, 0, 0], [0, 1, 0], [-1, -1, 0]]); Q = P * [1, -1, 1]
+    Rg, _ = api.solve_svd(P, Q); Ro, _ = O.solve_svd(P, Q)
+    assert np.abs(Rg - Ro).max() < 1e-12 and abs(np.linalg.det(Rg) - 1) < 1e-12
+    # degenerate sample (all three points equal): identity rotation in both
+    P = np.ones((3, 3)); Q = P + 2
+    Rg, tg = api.solve_svd(P, Q); Ro, to = O.solve_svd(P, Q)
+    assert np.array_equal(Rg, np.eye(3)) and np.array_equal(Ro, np.eye(3)) and np.allclose(tg, 2) and np.allclose(to, 2)
+    nodes1 = rng.uniform(-40, 40, size=(30, 3)); nodes2 = O.se3_act(T, nodes1)
+    idx = rng.permutation(30)[:12]
+    m1, m2 = nodes1[idx].copy(), nodes2[idx].copy()
+    m2[:4] += rng.normal(size=(4, 3)) * 3  # a third of the matches is wrong
+    for seed in (1, 7, 20251031):
+        Rg, tg, sg, bg = api.ransac_alignment(m1, m2, nodes1, nodes2, 500, seed)
+        Ro, to, so, bo = O.ransac_alignment(m1, m2, nodes1, nodes2, 500, seed)
+        assert (sg, bg) == (so, bo) and np.abs(Rg - Ro).max() < 1e-12 and np.abs(tg - to).max() < 1e-10
+        assert bg == 30 and np.abs(Rg @ nodes1.T + tg[:, None] - nodes2.T).max() < 1e-9
+
+
+def test_find_ins_match_is_exact_on_equal_graphs():
+    """The matching rule itself (5-NN on descriptors, label, sub-triangles), both sides fed the SAME graphs."""
+    for ka, kb in ((5, 3), (12, 12), (30, 27)):
+        ga, gb = O.build_graph(_boxes_of(ka)), O.build_graph(_boxes_of(kb))
+        ga["boxes"], gb["boxes"] = _boxes_of(ka), _boxes_of(kb)
+        mo, mg = O.find_ins_match(ga, gb), api.find_ins_match(ga, gb)
+        assert np.array_equal(mo, mg) and mo[:, 0].sum() >= 3
+        assert sorted(mo[:, 1].tolist()) == list(range(len(ga["boxes"])))  # every frame node exactly once
+        matched = mo[mo[:, 0] == 1]
+        assert np.array_equal(ga["boxes"][matched[:, 1], 6], gb["boxes"][matched[:, 2], 6])  # labels agree
+    # empty map: everything unmatched, in frame order (GraphMap.cpp:92-97); fewer than 5 map nodes: index 0 fills the result
+    empty = dict(boxes=np.zeros((0, 8)), desc=np.zeros((0, 120), np.float32), tri_counts=np.zeros(0, np.int32), triangles=np.zeros((0, 3)))
+    mo, mg = O.find_ins_match(ga, empty), api.find_ins_match(ga, empty)
+    assert np.array_equal(mo, mg) and not mo[:, 0].any() and mo[:, 1].tolist() == list(range(len(ga["boxes"])))
+    few = {k: (v[:3] if k != "triangles" else v[:int(gb["tri_counts"][:3].sum())]) for k, v in gb.items() if k in ("boxes", "desc", "tri_counts", "triangles")}
+    assert np.array_equal(O.find_ins_match(ga, few), api.find_ins_match(ga, few))
+
+
+def test_graph_map_tracking_agrees_with_oracle(ctx_small):
+    """A tracked sequence.  The spectral half of the node descriptors is not unique (a scan's adjacency matrix is
+    nearly all ones: eigenvalue 0 with multiplicity n-1), so two eigen-solvers - the reference's Eigen
+    included - may pick different neighbours for a few nodes.  What must agree: how many nodes match, which nodes
+    found the map new, the instance set (labels, point counts), positions up to the averaging of a differently
+    matched pair, and the pruning."""
+    ctx_small.GraphMapClear()
+    gm = O.GraphMap()  # kitti launch values: nn 2 m / 2 m, range 100 m
+    differing = total = 0
+    for k in list(range(14)) + [40, 41, 42]:  # the jump prunes instances that fell out of range
+        boxes = _boxes_of(k)
+        pose = synth.gt_pose(k)
+        mo, fo = gm.track(boxes, pose)
+        mg, fg = ctx_small.GraphMapTrack(boxes, pose)
+        assert mo.shape == mg.shape and abs(int(mo[:, 0].sum()) - int(mg[:, 0].sum())) <= 1
+        differing += len({tuple(r) for r in mo.tolist()} ^ {tuple(r) for r in mg.tolist()}) // 2
+        total += len(mo)
+        assert sorted(fo.tolist()) == sorted(fg.tolist()), f"scan {k}: new instances differ"  # (a spurious match that fails
+        io, ig = gm.instances(), ctx_small.GraphMapInstances()                                 # the distance test moves a node back in the order)
+        assert io.shape == ig.shape  # (ids are drawn before the duplicate test, GraphMap.cpp:196-199, so they follow the order)
+        used = set()
+        for row in io:  # one-to-one by class and position, within the distance that lets two nodes be averaged
+            d = np.where(ig[:, 0] == row[0], np.linalg.norm(ig[:, 2:5] - row[2:5], axis=1), np.inf)
+            j = int(np.argmin(d))
+            assert d[j] < 2.0 and j not in used and ig[j, 8] == row[8]
+            used.add(j)
+    assert differing <= 0.08 * total and len(io) > 10
+    assert np.linalg.norm(io[:, 2:5] - synth.gt_pose(42)[4:], axis=1).max() <= 100.0  # range pruning
+    # a frame seen from an unknown pose: both find a transform close to the truth
+    boxes = _boxes_of(44)
+    oko, po, so, no = gm.relocalize(boxes, 0.4, 11)
+    okg, pg, sg, ng = ctx_small.Relocalization(boxes, 0.4, 11)
+    assert oko and okg and abs(no - ng) <= 2
+    for p in (po, pg):
+        et, er = pose_err(synth.gt_pose(44), p)
+        assert et < 1.0 and er < 0.05  # node centres of partial views: decimetres, good enough as an initial guess
+    ctx_small.GraphMapClear()
+    assert len(ctx_small.GraphMapInstances()) == 0
+
+
+def test_pipeline_with_relocalization_agrees_with_oracle():
+    """The relocalization preset (launch thresholds 0.12 m / 0.01 rad, inlier rate 0.37): on the synthetic drive the
+    model deviation trips several times while the motion model is still warming up, so the pose is re-estimated
+    from the matched instance nodes and registered again.  Up to the first relocalization the two pipelines must
+    agree to the pose tolerance; afterwards their graph-matched guesses may differ in principle (non-unique
+    spectral descriptors, see the tracking test), so the bar is 5 cm there."""
+    ctx = api.Context(api.preset("relocalization", max_points=1 << 18, map_capacity_log2=17))
+    slam = O.Slam(O.kitti_config(max_range=80.0, relocalization_enable=1, inlier_rate_th=0.37))
+    relocalized_once = False
+    for k in list(range(12)) + list(range(14, 20)):
+        _, xyz, lab = _scan(k, "hdl64")
+        rg = ctx.mainProcess(xyz, lab)
+        ro = slam.process(xyz, lab)
+        info = slam.graphmap_info()
+        st = ctx.stats()
+        et, er = pose_err(ro["pose"], rg["pose"])
+        if not relocalized_once:
+            assert st.relocalization_attempts == info["attempts"], k  # same poses so far -> same model deviation -> same decision
+            assert rg["relocalized"] == info["relocalized"], k
+        relocalized_once = relocalized_once or rg["relocalized"] or info["relocalized"]
+        if relocalized_once:
+            assert et < 0.05 and er < 0.005, (k, et, er)
+        else:
+            assert et < POSE_TOL_M and er < POSE_TOL_RAD, (k, et, er)
+    assert relocalized_once and st.relocalizations >= 1 and info["relocalizations"] >= 1
+    assert abs(st.relocalization_attempts - info["attempts"]) <= 1
+    assert abs(len(ctx.GraphMapInstances()) - info["instances"]) <= 3
+    ctx.close()

@@ -444,3 +444,51 @@ def test_scan_descriptor_known_answers():
     assert b[0] / b[47] == pytest.approx(2.0, rel=1e-6)        # two occupied sectors against one (5.5 and 5.6 share sector 0)
     assert np.linalg.norm(d) == pytest.approx(1.0, abs=1e-6)
     assert np.linalg.norm(g) == pytest.approx(np.linalg.norm(b), rel=1e-6)  # both halves are unit vectors before the final scaling
+
+
+def test_graph_map_and_relocalization_known_answers():
+    """frontend/GraphMap.cpp + core/CommonUtils.cpp restated: hand-checkable behaviour."""
+    rng = np.random.default_rng(9)
+    # SolveSVD recovers a rigid transform exactly from 3 and from many pairs, det = +1
+    T = O.se3_exp([0.5, -1.0, 0.3, 0.1, -0.2, 0.4])
+    for n in (3, 10):
+        P = rng.normal(size=(n, 3)) * 5
+        R, t = O.solve_svd(P, O.se3_act(T, P))
+        assert np.abs(R @ P.T + t[:, None] - O.se3_act(T, P).T).max() < 1e-12 and abs(np.linalg.det(R) - 1) < 1e-12
+    # RANSAC with a third of the matches wrong still finds the transform that explains every node
+    nodes1 = rng.uniform(-40, 40, size=(30, 3)); nodes2 = O.se3_act(T, nodes1)
+    idx = rng.permutation(30)[:12]
+    m1, m2 = nodes1[idx].copy(), nodes2[idx].copy()
+    m2[:4] += rng.normal(size=(4, 3)) * 3
+    R, t, score, best = O.ransac_alignment(m1, m2, nodes1, nodes2, 500, 7)
+    assert best == 30 and score == 1.0 and np.abs(R @ nodes1.T + t[:, None] - nodes2.T).max() < 1e-9
+    assert O.ransac_alignment(m1, m2, nodes1, nodes2, 500, 7)[3] == best  # seeded: reproducible
+    # a static scene of well separated instances: first scan adds them, second scan matches them all, none is added twice
+    def box(x, y, label, pts=80):
+        return [x, y, 0.5, 2.0, 2.0, 1.5, label, pts]
+    scene = np.array([box(10 * i, 7 * (i % 3) - 5, 1 + i % 3) for i in range(12)], dtype=np.float64)
+    gm = O.GraphMap(nn_vehicle=1.0, nn_pole=1.0, max_distance=150.0)
+    ident = O.se3_exp([0] * 6)
+    m, fresh = gm.track(scene, ident)
+    assert not m[:, 0].any() and fresh.tolist() == list(range(12)) and len(gm.instances()) == 12
+    m, fresh = gm.track(scene, ident)
+    assert m[:, 0].all() and len(fresh) == 0 and len(gm.instances()) == 12
+    assert np.array_equal(m[:, 1], m[:, 2])  # every node found itself
+    # too small / too few points are not admitted (GraphMap.cpp:185-191); a second one of the same class nearby neither
+    extra = np.array([box(200, 0, 1, pts=20), [210, 0, 0.5, 0.5, 2, 2, 1, 80], [220, 0, 0.5, 2, 2, 0.5, 2, 80], box(10.5, 2.2, 2)])
+    m, fresh = gm.track(np.concatenate([scene, extra]), ident)
+    assert len(gm.instances()) == 12 and len(fresh) == 0
+    # moving 200 m away drops what is farther than max_distance from the sensor
+    far = O.se3_exp([200.0, 0, 0, 0, 0, 0])
+    gm.track(np.zeros((0, 8)), far)
+    inst = gm.instances()
+    assert 0 < len(inst) < 12 and np.linalg.norm(inst[:, 2:5] - [200, 0, 0], axis=1).max() <= 150.0 and inst[:, 2].min() >= 50.0
+    # relocalization: the scene seen from a displaced pose gives back that pose
+    gm = O.GraphMap(nn_vehicle=1.0, nn_pole=1.0, max_distance=200.0)
+    gm.track(scene, ident)
+    Tq = O.se3_exp([3.0, -2.0, 0.0, 0, 0, 0.3])
+    seen = scene.copy()
+    seen[:, :3] = O.se3_act(O.se3_inv(Tq), scene[:, :3])
+    ok, pose, score, nm = gm.relocalize(seen, 0.4, 5)
+    assert ok and nm >= 4 and score > 0.9
+    assert np.abs(O.se3_act(pose, seen[:, :3]) - scene[:, :3]).max() < 1e-6
