@@ -327,4 +327,95 @@ inline Graph BuildGraph(const std::vector<Bbox> &cluster_boxes, double edge_dis_
     return g;
 }
 
+// ---- loopclosure/LoopClosure.hpp:50 GenScanDescriptors(graph, edge_dis_th, subinterval): 6*subinterval+3 graph part +
+// 48 background part.  graph.back_points is what ClusterPoints returned as background_points (SemGraphSLAM.cpp:50).
+inline std::vector<float> GenScanDescriptors(const Graph &graph, double edge_dis_th, int subinterval) {
+    std::vector<float> out((size_t)(6 * subinterval + 3 + 48), 0.f);
+    sgs_ctx *c = HipContext::instance().get();
+    if (!c) return out;
+    const int nb = (int)graph.node_labels.size();
+    std::vector<double> boxes(8 * (size_t)nb);
+    for (int i = 0; i < nb; ++i) {
+        double *b = &boxes[8 * (size_t)i];
+        for (int k = 0; k < 3; ++k) { b[k] = graph.node_centers[(size_t)i][k]; b[3 + k] = graph.node_dimensions[(size_t)i][k]; }
+        b[6] = graph.node_labels[(size_t)i];
+        b[7] = graph.points_num[(size_t)i];
+    }
+    int n = 0;
+    const Vec3 none{};
+    ok(c, sgs_gen_scan_descriptor(c, boxes.data(), nb, graph.back_points.first.empty() ? none.data() : graph.back_points.first[0].data(),
+                                  graph.back_points.second.data(), (int)graph.back_points.first.size(), edge_dis_th, subinterval,
+                                  out.data(), (int)out.size(), &n), "GenScanDescriptors");
+    return out;
+}
+
+// ---- loopclosure/FastIcp.hpp:40-105.  get_trans takes / returns poses here; with Eigen the reference's Matrix4d
+// overload is provided on top.
+class FastIcp {
+public:
+    FastIcp(float voxel_size_map, int max_points_per_voxel) : voxel_(voxel_size_map), cap_(max_points_per_voxel) {}
+    Pose get_trans(const V3d_i &cloudA, const V3d_i &cloudB, const Pose &initTrans) {
+        sgs_ctx *c = HipContext::instance().get();
+        if (!c) return initTrans;
+        auto fuse = [](const V3d_i &f) {
+            std::vector<double> v(4 * f.first.size());
+            for (size_t i = 0; i < f.first.size(); ++i) { v[4 * i] = f.first[i][0]; v[4 * i + 1] = f.first[i][1]; v[4 * i + 2] = f.first[i][2]; v[4 * i + 3] = f.second[i]; }
+            return v;
+        };
+        const std::vector<double> a = fuse(cloudA), b = fuse(cloudB);
+        double g[7], out[7];
+        pose_to7(initTrans, g);
+        int it = 0;
+        if (!ok(c, sgs_fast_icp(c, a.data(), (int)cloudA.first.size(), b.data(), (int)cloudB.first.size(), g, voxel_, cap_, 0.5, out, &it),
+                "FastIcp::get_trans"))
+            return initTrans;
+        return pose_from7(out);
+    }
+#if SGS_FACADE_WITH_EIGEN
+    Eigen::Matrix4d get_trans(const V3d_i &cloudA, const V3d_i &cloudB, const Eigen::Matrix4d &initTrans) {
+        const Pose T = get_trans(cloudA, cloudB, Pose(initTrans.block<3, 3>(0, 0), initTrans.block<3, 1>(0, 3)));
+        Eigen::Matrix4d M = Eigen::Matrix4d::Identity();
+        M.block<3, 3>(0, 0) = T.rotationMatrix();
+        M.block<3, 1>(0, 3) = T.translation();
+        return M;
+    }
+#endif
+private:
+    float voxel_;
+    int cap_;
+};
+
+// ---- frontend/GraphMap.hpp:23-71 (the instance map lives in the context; Graph::new_instance is the second result)
+using VTbii = std::vector<std::tuple<bool, int, int>>;
+struct GraphMap {
+    // FindInsMatch + Update in one step, as mainProcess uses them (SemGraphSLAM.cpp:54,116)
+    VTbii Track(const Graph &graph, const Pose &pose, std::vector<int> *new_instance = nullptr) {
+        VTbii out;
+        sgs_ctx *c = HipContext::instance().get();
+        const int nb = (int)graph.node_labels.size();
+        if (!c) return out;
+        std::vector<double> boxes(8 * (size_t)nb);
+        for (int i = 0; i < nb; ++i) {
+            double *b = &boxes[8 * (size_t)i];
+            for (int k = 0; k < 3; ++k) { b[k] = graph.node_centers[(size_t)i][k]; b[3 + k] = graph.node_dimensions[(size_t)i][k]; }
+            b[6] = graph.node_labels[(size_t)i];
+            b[7] = graph.points_num[(size_t)i];
+        }
+        std::vector<int32_t> m(3 * (size_t)nb + 3), fresh((size_t)nb + 1);
+        double p7[7];
+        pose_to7(pose, p7);
+        int nn = 0;
+        if (!ok(c, sgs_graph_map_track(c, boxes.data(), nb, p7, m.data(), fresh.data(), &nn), "GraphMap::Track")) return out;
+        for (int i = 0; i < nb; ++i) out.emplace_back(m[3 * (size_t)i] != 0, m[3 * (size_t)i + 1], m[3 * (size_t)i + 2]);
+        if (new_instance) new_instance->assign(fresh.begin(), fresh.begin() + nn);
+        return out;
+    }
+    size_t size() const {
+        sgs_ctx *c = HipContext::instance().get();
+        int n = 0;
+        if (c) sgs_graph_map_instances(c, nullptr, 0, &n);
+        return (size_t)n;
+    }
+};
+
 }  // namespace graph_slam

@@ -38,6 +38,26 @@ int main() {
     const Graph g = BuildGraph(boxes, 60.0, 30, 30, 20.0);
     std::printf("facade cropped %zu ds %zu boxes %zu graph nodes %zu map points %zu\n", cropped.first.size(), ds.first.size(),
                 boxes.size(), g.node_desc.size(), map.Pointcloud().size());
+    // back-end hooks: scan descriptor, loop-pair refinement, instance tracking
+    Graph g2 = g;
+    g2.back_points = bg;
+    const std::vector<float> sd = GenScanDescriptors(g2, 60.0, 30);
+    V3d_i A, B;
+    for (size_t i = 0; i < scene.size(); i += 3) { Vec3 q; q[0] = scene[i][0]; q[1] = scene[i][1]; q[2] = scene[i][2]; B.first.push_back(q); B.second.push_back(0); }
+    for (size_t i = 0; i < B.first.size(); i += 2) { Vec3 q = B.first[i]; q[0] -= 0.1; q[1] += 0.05; A.first.push_back(q); A.second.push_back(0); }
+    FastIcp ficp(1.0f, 5);
+    double f[7];
+    pose_to7(ficp.get_trans(A, B, Pose()), f);
+    const bool ficp_ok = std::fabs(f[4] - 0.1) < 1e-6 && std::fabs(f[5] + 0.05) < 1e-6;
+    GraphMap gm;
+    std::vector<int> fresh;
+    const VTbii first = gm.Track(g2, Pose(), &fresh);
+    const VTbii second = gm.Track(g2, Pose(), nullptr);
+    size_t matched = 0;
+    for (const auto &m : second) matched += std::get<0>(m) ? 1 : 0;
+    std::printf("facade scan descriptor %zu floats, fast icp t = %.6f %.6f, graph map %zu instances, %zu new, %zu of %zu matched again\n", sd.size(),
+                f[4], f[5], gm.size(), fresh.size(), matched, second.size());
+    if (sd.size() != 231 || !ficp_ok || first.size() != boxes.size() || gm.size() != fresh.size() || matched < gm.size()) { std::printf("facade FAILED\n"); return 4; }
     std::printf(good && !cropped.first.empty() && ds.first.size() <= cropped.first.size() ? "facade ok\n" : "facade FAILED\n");
     return good ? 0 : 1;
 }
