@@ -938,3 +938,40 @@ def test_pipeline_with_relocalization_agrees_with_oracle():
     assert abs(st.relocalization_attempts - info["attempts"]) <= 1
     assert abs(len(ctx.GraphMapInstances()) - info["instances"]) <= 3
     ctx.close()
+
+
+def test_pipeline_degenerate_scans_in_the_chained_stream():
+    """Scans that crop to nothing, scans with a handful of points and a full scan again, through the prefetching /
+    asynchronous pipeline and through the oracle: same sizes, same poses, nothing hangs."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    full = [synth.scan(k, "small") for k in range(8)]
+    n_full = len(full[0][0])
+    near = np.zeros((n_full, 4), dtype=np.float32); near[:, 0] = 1.0          # everything inside min_range: crops to nothing
+    few = np.zeros((n_full, 4), dtype=np.float32); few[:40, :3] = full[3][0][:40 * 50:50, :3]  # 40 real points, the rest at the origin
+    seq = [(full[0][0], full[0][2]), (full[1][0], full[1][2]), (full[2][0], full[2][2]), (near, full[0][2]), (few, full[3][2]),
+           (full[4][0], full[4][2]), (near, full[0][2]), (full[5][0], full[5][2]), (full[6][0], full[6][2])]
+
+    def dev(a):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), a.nbytes) == 0 and hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+        return p
+    d = [(dev(np.ascontiguousarray(x, dtype=np.float32)), dev(np.ascontiguousarray(l, dtype=np.int32))) for x, l in seq]
+    ctx = make_ctx(async_map_update=1)
+    slam = O.Slam(O.kitti_config())
+    res = api.SgsScanResult()
+    for k, (x, l) in enumerate(seq):
+        if k + 1 < len(seq):
+            ctx.prefetch_scan_dev(d[k + 1][0].value, d[k + 1][1].value, n_full, "")
+        ctx.process_scan_dev(d[k][0].value, d[k][1].value, n_full, None, "", res)
+        ro = slam.process(x[:, :3].astype(np.float64), l)
+        assert (res.n_in, res.n_cluster, res.n_ds, res.n_src) == (ro["n_in"], ro["n_cluster"], ro["n_ds"], ro["n_src"]), k
+        et, er = pose_err(ro["pose"], np.array(res.pose[:]))
+        assert et < POSE_TOL_M and er < POSE_TOL_RAD, (k, et, er)
+    assert ctx.stats().icp_fallbacks == 0
+    assert ctx.map_size() == slam.map().size()
+    ctx.close()
+    for a, b in d:
+        hip.hipFree(a); hip.hipFree(b)
