@@ -54,6 +54,31 @@ def main():
     np.savez_compressed(os.path.join(HERE, "mini_sequence.npz"), frames=np.array(FRAMES), poses=np.array(poses),
                         counts=np.array(counts, dtype=np.int64), last_boxes=boxes_all[-1],
                         n_boxes=np.array([len(b) for b in boxes_all]), **clouds)
+    # (c) rows beyond the hot path: scan descriptor of the last frame, a loop-pair refinement, SolveSVD /
+    # seeded RANSAC on a fixed point set
+    cx, cl = slam.cloud(1)
+    desc = O.scan_descriptor(boxes_all[-1], cx, cl)
+
+    def ds_cloud(k):
+        xyzi, raw, lab = synth.scan(k, SHAPE)
+        px, pl = O.preprocess(xyzi[:, :3].astype(np.float64), lab, 100.0, 5.0)
+        dx, dl, _, _ = O.voxel_downsample(px, pl, 0.5)
+        return np.concatenate([dx, dl[:, None].astype(np.float64)], axis=1)
+    A, B = ds_cloud(5), ds_cloud(3)
+    init = O.se3_mul(O.se3_mul(O.se3_inv(synth.gt_pose(3)), synth.gt_pose(5)), O.se3_exp([0.1, -0.05, 0.0, 0, 0, 0.005]))
+    ficp_pose, ficp_info = O.fast_icp(A, B, init, 1.0, 5, 0.5)
+    rng = np.random.default_rng(20251031)
+    T = O.se3_exp([0.5, -1.0, 0.3, 0.1, -0.2, 0.4])
+    nodes1 = rng.uniform(-40, 40, size=(24, 3)); nodes2 = O.se3_act(T, nodes1)
+    idx = rng.permutation(24)[:10]
+    m1, m2 = nodes1[idx].copy(), nodes2[idx].copy()
+    m2[:3] += rng.normal(size=(3, 3)) * 3
+    R, t, score, best = O.ransac_alignment(m1, m2, nodes1, nodes2, 500, 7)
+    Rs, ts = O.solve_svd(m1[3:], m2[3:])
+    np.savez_compressed(os.path.join(HERE, "next_rows.npz"), scan_descriptor=desc, ficp_a=A, ficp_b=B, ficp_init=init, ficp_pose=ficp_pose,
+                        ficp_iterations=np.array(ficp_info["iterations"]), nodes1=nodes1, nodes2=nodes2, match1=m1, match2=m2,
+                        ransac_R=R, ransac_t=t, ransac_score=np.array(score), ransac_best=np.array(best), svd_R=Rs, svd_t=ts,
+                        svd_truth=T)
     print("wrote", os.listdir(HERE))
 
 
