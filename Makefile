@@ -24,6 +24,12 @@ build/%.o: $(PKG)/csrc/%.hip $(HIP_HDRS)
 $(PKG)/lib/libsgs_hip.so: $(HIP_OBJS)
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
+# diagnostic build of the library with per-phase device timers in the one-launch Gauss-Newton kernel
+# (tools/icp_phase_times.py loads it instead of the product library)
+timing: $(PKG)/lib/libsgs_hip_timing.so
+$(PKG)/lib/libsgs_hip_timing.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) $(HIPFLAGS) -DSGS_ICP_TIMING -shared -o $@ $(HIP_SRCS)
 clean:
 	rm -f $(PKG)/lib/*.so oracle/liboracle.so
-.PHONY: all oracle synth hip clean
+.PHONY: all oracle synth hip timing clean

@@ -19,7 +19,7 @@ u32 = ctypes.c_uint32
 SGS_OK, SGS_EINVAL, SGS_EHIP, SGS_ENOMEM, SGS_ECAPACITY = 0, -1, -2, -3, -4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsgs_hip.so")
+LIB_PATH = os.environ.get("SGS_HIP_LIB") or os.path.join(_HERE, "lib", "libsgs_hip.so")  # SGS_HIP_LIB: experiment builds
 
 # every symbol include/sgs.h declares
 ABI_SYMBOLS = [

@@ -260,12 +260,21 @@ __device__ inline void normal_equations(const double *S, double *A /*[36]*/, dou
     for (int i = 0; i < 6; ++i) b[i] = S[10 + i];
 }
 
-// LDS words of the solve tail
-struct SolveLds {
-    double A[36];
-    double rhs[6];
-    double x[6];
-};
+// element (i,j) of that matrix straight from the moment sums (any lane, any i and j): the solve below lets every
+// lane fetch its own element instead of one lane laying the matrix out first.  Same values bit for bit (the only
+// arithmetic is the sum of two moments on the rotational diagonal, and addition commutes).
+__device__ inline double system_element(const double *S, int i, int j) {
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    if (b < 3) return a == b ? S[0] : 0.0;
+    if (a < 3) {  // sum w * (-hat(s)), row a, column b - 3
+        const int d = b - 3 - a, dd = d < 0 ? d + 3 : d;
+        if (dd == 0) return 0.0;
+        return dd == 1 ? S[1 + (a + 2) % 3] : -S[1 + (a + 1) % 3];
+    }
+    const int p = a - 3, q = b - 3;  // sum w * (|s|^2 I - s s^T)
+    if (p == q) return S[4 + (p + 1) % 3] + S[4 + (p + 2) % 3];
+    return -S[6 + p + q];
+}
 
 // order LDS traffic between lanes of ONE wave (LDS operations of a wave execute in order; this only
 // keeps the compiler from moving them and waits for the data)
@@ -280,7 +289,7 @@ __device__ inline void wave_lds_sync() {
 //  * Pivoting: Eigen's left-looking LDLT picks the k-th pivot as the first largest |diagonal| among
 //    rows k..5 of the matrix as permuted so far - those diagonal entries are still the ORIGINAL ones,
 //    so the whole pivot sequence is a selection sort of the original diagonal.  Every lane replays
-//    that sort (uniform, in registers) and loads its element of B = P A P^T from LDS.
+//    that sort (uniform, in registers) and works out its element of B = P A P^T from the moment sums.
 //  * Factorisation: right-looking rank-1 updates with ds_bpermute broadcasts of column k; one
 //    reciprocal per pivot.  A zero pivot leaves its column undivided and contributes nothing, a
 //    |D_i| <= DBL_MIN gives x_i = 0 (Eigen's pseudo-inverse rule), an all-zero system gives x = 0.
@@ -304,12 +313,17 @@ __device__ inline double bcast_lane(double v) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__device__ inline void wave_solve6(SolveLds &L, int lane) {
+__device__ inline void wave_solve6(const double *S /*shared: the moment sums*/, double *x /*shared [6]*/, int lane) {
     // --- pivot sequence: selection sort (first maximum wins) on |diag| ---
     double mag[6];
     int id[6];
+    {
+        const double W = fabs(S[0]), xx = S[4], yy = S[5], zz = S[6];
+        mag[0] = mag[1] = mag[2] = W;
+        mag[3] = fabs(yy + zz); mag[4] = fabs(zz + xx); mag[5] = fabs(xx + yy);
+    }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { mag[i] = fabs(L.A[i * 7]); id[i] = i; }
+    for (int i = 0; i < 6; ++i) id[i] = i;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         double best = mag[k];
@@ -331,8 +345,8 @@ __device__ inline void wave_solve6(SolveLds &L, int lane) {
     int pi = id[0], pj = id[0];
 #pragma unroll
     for (int t = 1; t < 6; ++t) { pi = (i == t) ? id[t] : pi; pj = (j == t) ? id[t] : pj; }
-    double B = L.A[pi * 6 + pj];
-    double y = L.rhs[pi];
+    double B = system_element(S, pi, pj);  // B = P A P^T
+    double y = -S[10 + pi];                // right-hand side -J^T r, permuted
     // --- right-looking LDL^T ---
     double dinv = 0.0;  // lane (i,*): 1 / D_i, 0 where |D_i| <= DBL_MIN
     auto ldlt_step = [&](auto kc) {
@@ -372,7 +386,7 @@ __device__ inline void wave_solve6(SolveLds &L, int lane) {
     bwd_step(std::integral_constant<int, 3>{}); bwd_step(std::integral_constant<int, 2>{});
     bwd_step(std::integral_constant<int, 1>{});
     // x = P^T y
-    if (lane < 36 && i == j) L.x[pi] = y;
+    if (lane < 36 && i == j) x[pi] = y;
 }
 
 // 6x6 solve + SE3 update + convergence test of one Gauss-Newton iteration (F/Registration.cpp:
@@ -388,21 +402,14 @@ __device__ inline TailState load_tail_state(const DevState *st) {
     return TailState{st->T_icp, st->T_total, st->icp_corr, st->icp_cand, st->icp_probe, st->icp_iter, st->icp_max_iter};
 }
 
-__device__ inline void solve_and_update(DevState *st, const TailState &ts, const double *S, SolveLds &L, int lane,
+__device__ inline void solve_and_update(DevState *st, const TailState &ts, const double *S, double *x_lds, int lane,
                                         HostMirror *mirror) {
-    if (lane == 0) {
-        double b[6];
-        normal_equations(S, L.A, b);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) L.rhs[i] = -b[i];
-    }
-    wave_lds_sync();
-    wave_solve6(L, lane);
+    wave_solve6(S, x_lds, lane);
     wave_lds_sync();
     if (lane > 1) return;
     double x[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) x[i] = L.x[i];
+    for (int i = 0; i < 6; ++i) x[i] = x_lds[i];
     // estimation.log().norm() < 1e-4 (F/Registration.cpp:169): log(exp(x)) == x for |omega| < pi, so
     // the squared 6-vector norm of the update itself is compared with 1e-8
     double nn = 0.0;
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
     }
     __shared__ double red[kIcpThreads / 64][kIcpSums];
     __shared__ double S[kIcpSums];
-    __shared__ SolveLds solve_lds;
+    __shared__ double solve_x[6];
     __shared__ int is_last;
     if (lane == 0) {
 #pragma unroll
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
     TailState ts{};
     if (wave == 0) ts = load_tail_state(st);
     fold_partials<kIcpThreads / 64>(partials, S);
-    if (wave == 0) solve_and_update(st, ts, S, solve_lds, lane, mirror);
+    if (wave == 0) solve_and_update(st, ts, S, solve_x, lane, mirror);
 }
 
 // ---- the whole Gauss-Newton loop in ONE launch -------------------------------------------------------
@@ -548,6 +555,17 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
 // nevertheless run out (many contexts on one GPU), the block raises the abort bit in the counter, every
 // block leaves, and the host repeats the registration with one launch per iteration.
 constexpr uint32_t kAbortBit = 1u << 30;
+#ifdef SGS_ICP_TIMING
+// diagnostic build only (make timing, tools/icp_phase_times.py): per block and iteration the 10-ns ticks spent in
+// accumulate / inter-block wait / fold / solve, as thread 0 sees them
+constexpr int kDbgIters = 32;
+__device__ uint32_t g_icp_dbg[kDbgIters * kIcpBlocks * 8];
+#define SGS_STAMP_SET(var) var = wall_clock64()
+#define SGS_STAMP(var) const unsigned long long var = wall_clock64()
+#else
+#define SGS_STAMP(var)
+#define SGS_STAMP_SET(var)
+#endif
 constexpr uint32_t kSpinLimit = 1u << 21;
 
 template <bool SHARDED>
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     const float reach = (float)max_corr + 1e-3f;
     __shared__ double red[kIcpThreads / 64][kIcpSums];
     __shared__ double S[kIcpSums];
-    __shared__ SolveLds solve_lds;
+    __shared__ double solve_x[6];
     // state only thread 0 / the solving lanes need stays in LDS: the kernel is short of scalar registers
     __shared__ Rigid s_T[2];         // [0] T_icp, [1] T_total
     __shared__ long long s_cnt[3];   // correspondences, candidates, probes summed over the iterations
@@ -606,6 +624,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     int it = 0;
     bool done = false;
     while (it < max_iter) {
+        SGS_STAMP(ts0);
         double acc[kIcpSums];
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
@@ -643,6 +662,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
             for (int k = 0; k < kIcpSums; ++k) red[wave][k] = acc[k];
         }
         __syncthreads();
+        SGS_STAMP(ts1);
         // partials alternate between two buffers: a block can be at most one iteration ahead of another
         double *buf = partials2 + (size_t)(it & 1) * kIcpSums * kIcpBlocks;
         if (wave == 0) {
@@ -686,21 +706,21 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
             if (threadIdx.x == 0 && mirror) __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
+        SGS_STAMP(ts2);
         fold_partials<kIcpThreads / 64>(buf, S);
+        SGS_STAMP(ts3);
+#ifdef SGS_ICP_TIMING
+        unsigned long long ts3a = ts3, ts3b = ts3, ts3c = ts3;
+#endif
         if (wave == 0) {
-            if (lane == 0) {
-                double b[6];
-                normal_equations(S, solve_lds.A, b);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) solve_lds.rhs[i] = -b[i];
-            }
+            SGS_STAMP_SET(ts3a);
+            wave_solve6(S, solve_x, lane);
             wave_lds_sync();
-            wave_solve6(solve_lds, lane);
-            wave_lds_sync();
+            SGS_STAMP_SET(ts3b);
             if (lane <= 1) {
                 double x[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) x[i] = solve_lds.x[i];
+                for (int i = 0; i < 6; ++i) x[i] = solve_x[i];
                 double nn = 0.0;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
@@ -712,8 +732,17 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
                     s_cnt[0] += (long long)S[16]; s_cnt[1] += (long long)S[17]; s_cnt[2] += (long long)S[18];
                 }
             }
+            SGS_STAMP_SET(ts3c);
         }
         __syncthreads();
+#ifdef SGS_ICP_TIMING
+        if (threadIdx.x == 0 && it < kDbgIters) {
+            const unsigned long long ts4 = wall_clock64();
+            uint32_t *d = &g_icp_dbg[((size_t)it * kIcpBlocks + blockIdx.x) * 8];
+            d[0] = (uint32_t)(ts1 - ts0); d[1] = (uint32_t)(ts2 - ts1); d[2] = (uint32_t)(ts3 - ts2); d[3] = (uint32_t)(ts4 - ts3);
+            d[4] = (uint32_t)(ts3a - ts3); d[5] = (uint32_t)(ts3b - ts3a); d[6] = (uint32_t)(ts3c - ts3b); d[7] = (uint32_t)(ts4 - ts3c);
+        }
+#endif
         T_total = s_T[1];
         ++it;
         done = s_flag != 0;
@@ -840,6 +869,13 @@ void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const 
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out28_dev) {
     hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(256), 0, s, st, partials, kIcpBlocks, out28_dev);
 }
+
+#ifdef SGS_ICP_TIMING
+extern "C" int sgs_debug_icp_timing(uint32_t *out, int words) {  // diagnostic build only, not in include/sgs.h
+    const size_t want = sizeof(uint32_t) * (size_t)words, have = sizeof(g_icp_dbg);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_dbg), want < have ? want : have);
+}
+#endif
 
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
                             int32_t *found) {

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Development aid: compare experiment builds of the library (build/exp/libsgs_<tag>.so [+ _timing]) on the GPU box.
+#   bash tools/exp_waves.sh hdl64 base w5 w6       ("base" = the product library)
+cd "$(dirname "$0")/.."
+shape=$1; shift
+for tag in "$@"; do
+  if [ "$tag" = base ]; then lib=$PWD/sg-slam_amd/lib/libsgs_hip.so; tlib=$PWD/sg-slam_amd/lib/libsgs_hip_timing.so
+  else lib=$PWD/build/exp/libsgs_$tag.so; tlib=$PWD/build/exp/libsgs_${tag}_timing.so; fi
+  echo "== $tag $shape"
+  SGS_HIP_LIB=$lib timeout -k 10 150 python bench.py --no-cpu-baseline --streams 0 --shape $shape > gpurun_out/exp_${tag}_$shape.log 2>&1 || { tail -5 gpurun_out/exp_${tag}_$shape.log; exit 1; }
+  python - <<P
+import json
+d=json.loads([x for x in open("gpurun_out/exp_${tag}_$shape.log") if x.startswith("{")][-1])
+print("scans/s", d["value"], "launch_us", d["roofline"]["avg_launch_us"], "iters", d["config"]["mean_icp_iterations"], "n_src", d["config"]["mean_n_src"])
+P
+  if [ -f $tlib ]; then SGS_HIP_LIB=$tlib timeout -k 10 150 python tools/icp_phase_times.py $shape 2>&1 | grep -v amdgpu.ids || exit 1; fi
+done

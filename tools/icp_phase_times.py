@@ -1,0 +1,55 @@
+"""Development aid: where an iteration of the one-launch Gauss-Newton kernel spends its time.
+
+Loads the diagnostic build of the library (`make timing` -> lib/libsgs_hip_timing.so) instead of the product one:
+its kernel leaves, per block and iteration, the 10-ns ticks thread 0 spent in accumulate / inter-block wait /
+fold / solve.  Prints per-iteration figures averaged over the scans: mean and max over blocks of the accumulate
+phase (the slowest block sets the pace of the iteration), the wait as the slowest block sees it, fold, solve.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from sg_slam_amd import api, synth  # noqa: E402
+
+SCANS, WARM, ITERS, BLOCKS = 80, 20, 32, 256  # kDbgIters, kIcpBlocks
+shape = sys.argv[1] if len(sys.argv) > 1 else "hdl64"
+dev = torch.device("cuda:0")
+api.LIB_PATH = os.environ.get("SGS_HIP_LIB") or api.LIB_PATH.replace("libsgs_hip.so", "libsgs_hip_timing.so")
+L = api.lib()
+fn = L.sgs_debug_icp_timing
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+ctx = api.Context(api.preset("kitti", max_points=1 << 20 if shape == "dense128" else 1 << 17, enable_graph=1), device=0)
+res = api.SgsScanResult()
+buf = np.zeros((ITERS, BLOCKS, 8), dtype=np.uint32)
+rows = []
+for k in range(SCANS):
+    xyzi, raw, _ = synth.scan(k, shape)
+    lab = api.remap_labels(raw)
+    d_x, d_l = torch.from_numpy(xyzi).to(dev), torch.from_numpy(lab).to(dev)
+    ctx.process_scan_dev(d_x.data_ptr(), d_l.data_ptr(), xyzi.shape[0], None, "", res)
+    torch.cuda.synchronize()
+    if k < WARM:
+        continue
+    assert fn(buf.ctypes.data, buf.size) == 0
+    it = min(res.icp_iterations, ITERS)
+    t = buf[:it].astype(np.float64) * 0.01  # us
+    acc, wait, fold, solve = t[..., 0], t[..., 1], t[..., 2], t[..., 3]
+    rows.append([res.n_src, it, acc.mean(), acc.max(axis=1).mean(), np.percentile(acc, 99), wait.min(axis=1).mean(), wait.mean(),
+                 fold.mean(), solve.mean(), t[..., :4].sum(axis=2).mean(),
+                 t[..., 4].mean(), t[..., 5].mean(), t[..., 6].mean(), t[..., 7].mean()])
+r = np.array(rows)
+names = ["sources", "iterations", "acc mean", "acc max-over-blocks", "acc p99", "wait of the last block", "wait mean", "fold", "solve",
+         "iteration total", "solve: build system", "solve: LDLT", "solve: exp + compose", "solve: block sync"]
+few = r[:, 0] <= 1024  # at most one query per wavefront
+print(f"{'':28s} {'all':>8s} {'n<=1024':>8s} {'n>1024':>8s}   ({int(few.sum())} / {int((~few).sum())} scans)")
+for k, n in enumerate(names):
+    a, b, c = r[:, k].mean(), r[few, k].mean() if few.any() else float("nan"), r[~few, k].mean() if (~few).any() else float("nan")
+    print(f"{n:28s} {a:8.2f} {b:8.2f} {c:8.2f}")
+ctx.close()
