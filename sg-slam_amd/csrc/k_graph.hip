@@ -330,8 +330,11 @@ __device__ __forceinline__ int neighbour_slot(const ClusterMem &M, int own, int 
     return -1;
 }
 
+// returns false (LDS only, uniformly over the block) when the cell table handed in turned out too small for the
+// class: nothing has been written outside the table's own memory then, and the caller runs the class again on a
+// table sized for the worst case
 template <bool LDS>
-__device__ __forceinline__ void cluster_class_body(const int c, const int n, const CloudView in, ClassParams *params,
+__device__ __forceinline__ bool cluster_class_body(const int c, const int n, const CloudView in, ClassParams *params,
                                                    const int32_t *__restrict__ order, const int32_t *__restrict__ pol_azi,
                                                    const double *__restrict__ apr_range, const double minR, const double maxR,
                                                    const ClusterConsts K, const ClusterMem M, ClusterStat *stat_out /*global, [v], v = 1..*/,
@@ -340,7 +343,7 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int32_t *const cslot = M.cslot, *const parent = M.parent;
     const int tmask = M.tmask, cap = tmask + 1;
-    __shared__ int s_current, s_ncells;
+    __shared__ int s_current, s_ncells, s_overflow;
 
     // ---- A: grid dimensions (:37-39)
     const int length = (int)((maxR - minR) / K.dR) + 1, width = K.width, height = K.height;
@@ -348,6 +351,7 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
         params[c].min_range = minR; params[c].max_range = maxR;
         params[c].length = length; params[c].width = width; params[c].height = height;
         s_ncells = 0;
+        s_overflow = 0;
     }
     for (int s = tid; s < cap; s += kCluThreads) { M.tkey[s] = INT_MIN; M.tmin[s] = INT_MAX; M.tlab[s] = -1; M.tswept[s] = 0; }
     __syncthreads();
@@ -358,22 +362,30 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
         const int rng = (int)((apr_range[j] - minR) / K.dR);
         const int vidx = (pol * length + rng) + azi * length * width;
         uint32_t s = cell_hash(vidx) & (uint32_t)tmask;
-        while (true) {
+        bool placed = false;
+        for (int step = 0; step <= tmask; ++step) {
             const int cur = atomicCAS(&M.tkey[s], INT_MIN, vidx);
             if (cur == INT_MIN) {  // this thread created the cell
                 M.tpol[s] = pol; M.trng[s] = rng; M.tazi[s] = azi;
                 const int ci = atomicAdd(&s_ncells, 1);
                 M.tcidx[s] = ci;
                 M.plabel[ci] = (int)s;  // dense list of the occupied slots (plabel is not in use before the walk)
+                placed = true;
                 break;
             }
-            if (cur == vidx) break;
+            if (cur == vidx) { placed = true; break; }
             s = (s + 1u) & (uint32_t)tmask;
+        }
+        if (!placed) {  // table full (only a table sized by a guess can be)
+            s_overflow = 1;
+            continue;
         }
         atomicMin(&M.tmin[s], j);
         cslot[j] = (int)s;
     }
     __syncthreads();
+    // a table sized by a guess (see the kernel) must stay sparse enough for the probes of the walk
+    if (LDS && (s_overflow || s_ncells > cap - cap / 4)) return false;
     // ---- C: neighbour lists of the occupied cells (27 lookups each), when they fit
     const bool lists = M.nbr != nullptr && s_ncells <= M.nbr_cells;
     if (lists) {
@@ -483,6 +495,7 @@ __device__ __forceinline__ void cluster_class_body(const int c, const int n, con
         __syncthreads();
         for (int v = 1 + tid; v <= current; v += kCluThreads) stat_out[v] = acc[v];
     }
+    return true;
 }
 
 // one workgroup per class; the working set lives in LDS when the class fits, else in global scratch
@@ -501,9 +514,16 @@ __global__ __launch_bounds__(kCluThreads) void cluster_class_kernel(CloudView in
     const int start = params[c].start;
     const double minR = dec_double(range_ext[2 * c]), maxR = dec_double(range_ext[2 * c + 1]);
     ClusterStat *stat_out = stat + start + c;  // indexed by label value 1..n
+    // The cell table in LDS: sized for one cell per point it holds classes of up to ~1360 points.  A class has several
+    // points per cell, so a larger class first tries the largest table that fits (down to a quarter of the worst case);
+    // the build notices when that was too optimistic and the class runs again on global scratch, which is what it
+    // would have done anyway (the walk is a chain of dependent loads: LDS or HBM decides 40 us or 400 us).
     int cap = 1;
     while (cap < n + n / 2 + 1) cap <<= 1;
+    const int worst = cap;
+    while (cap > worst / 4 && 3 * n + 1 + 8 * cap + 64 > kLdsWords) cap >>= 1;
     const int fixed = 3 * n + 1 + 8 * cap;
+    bool done = false;
     if (fixed + 64 <= kLdsWords) {
         ClusterMem M;
         M.cslot = smem;
@@ -518,9 +538,11 @@ __global__ __launch_bounds__(kCluThreads) void cluster_class_kernel(CloudView in
         M.nbr = rest;
         M.nbr_cells = room / 27;
         M.tmask = cap - 1;
-        cluster_class_body<true>(c, n, in, params, fg_order + start, pol_azi + 2 * (size_t)start, apr_range + start, minR, maxR, K,
-                                 M, stat_out, reinterpret_cast<ClusterStat *>(rest), room / 16 - 1, pt_cluster);
-    } else {
+        done = cluster_class_body<true>(c, n, in, params, fg_order + start, pol_azi + 2 * (size_t)start, apr_range + start, minR, maxR,
+                                        K, M, stat_out, reinterpret_cast<ClusterStat *>(rest), room / 16 - 1, pt_cluster);
+        if (!done) __syncthreads();  // every thread has read the verdict before the shared words are reused
+    }
+    if (!done) {
         ClusterMem M;
         M.cslot = cslot_all + start;
         M.plabel = plabel_all + start;

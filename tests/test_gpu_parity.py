@@ -470,6 +470,19 @@ def test_cluster_edge_cases(ctx_small):
     bo, pco, _, _ = O.cluster_points(big, lab, 2.0, 0.5, 2.0)
     bg, pcg, _, _ = ctx_small.ClusterPoints(big, lab, 2.0, 0.5, 2.0)
     assert np.array_equal(pco, pcg) and np.array_equal(bo, bg)
+    # a class past the one-cell-per-point LDS limit (~1360 points) whose points share cells: the smaller LDS table holds it
+    dense = np.concatenate([RNG.normal(size=(1500, 3)) * 0.5 + [12, 3, -0.5], RNG.normal(size=(1500, 3)) * 0.5 + [-9, -14, -0.3],
+                            RNG.normal(size=(800, 3)) * 0.4 + [25, -2, -0.8]])
+    lab = np.full(len(dense), 1, dtype=np.int32)
+    bo, pco, _, _ = O.cluster_points(dense, lab, 2.0, 0.5, 2.0)
+    bg, pcg, _, _ = ctx_small.ClusterPoints(dense, lab, 2.0, 0.5, 2.0)
+    assert np.array_equal(pco, pcg) and np.array_equal(bo, bg) and len(bo) >= 3
+    # the same size spread thin (about a cell per point): the LDS table overflows and the class reruns on global scratch
+    thin = RNG.uniform(-1, 1, size=(3000, 3)) * [60, 60, 0.6] + [0, 0, -1.0]
+    lab = np.full(len(thin), 16, dtype=np.int32)
+    bo, pco, _, _ = O.cluster_points(thin, lab, 2.0, 0.5, 2.0)
+    bg, pcg, _, _ = ctx_small.ClusterPoints(thin, lab, 2.0, 0.5, 2.0)
+    assert np.array_equal(pco, pcg) and np.array_equal(bo, bg)
     # random multi-class soup against the oracle
     xyz = RNG.normal(size=(4000, 3)) * [15, 15, 1.0] + [0, 0, -0.5]
     lab = RNG.choice([1, 4, 5, 16, 18, 9, 13, 0], size=4000).astype(np.int32)
