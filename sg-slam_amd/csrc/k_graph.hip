@@ -402,9 +402,12 @@ __device__ __forceinline__ bool cluster_class_body(const int c, const int n, con
         int current = 0;
         int last = -1;
         for (int base = 0; base < n; base += 64) {
+            // per window of 64 points: the cell slot of every point and that cell's neighbour-list row stay in
+            // registers, a seed step then starts with ONE dependent LDS read (the swept flags) instead of three
+            const int jj = base + lane;
+            const int sl = jj < n ? cslot[jj] : 0;
+            const int row = lists ? 27 * M.tcidx[sl] : 0;
             while (true) {
-                const int jj = base + lane;
-                const int sl = jj < n ? cslot[jj] : 0;
                 const bool unl = jj < n && jj > last && M.tswept[sl] != 1;
                 const unsigned long long um = __ballot(unl);
                 if (!um) break;
@@ -413,7 +416,7 @@ __device__ __forceinline__ bool cluster_class_body(const int c, const int n, con
                 last = i;
                 const int own = __builtin_amdgcn_readlane(sl, fl0);
                 int ns = -1;
-                if (lane < 27) ns = lists ? M.nbr[27 * M.tcidx[own] + lane] : neighbour_slot(M, own, lane, length, width, height);
+                if (lane < 27) ns = lists ? M.nbr[__builtin_amdgcn_readlane(row, fl0) + lane] : neighbour_slot(M, own, lane, length, width, height);
                 const bool exist = ns >= 0;
                 int lb = -1;
                 bool haslab = false;
