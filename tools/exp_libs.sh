@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development aid: compare experiment builds of the library (build/exp/libsgs_<tag>.so [+ _timing]) on the GPU box.
-#   bash tools/exp_waves.sh hdl64 base w5 w6       ("base" = the product library)
+#   bash tools/exp_libs.sh hdl64 base mytag       ("base" = the product library + lib/libsgs_hip_timing.so)
 cd "$(dirname "$0")/.."
 shape=$1; shift
 for tag in "$@"; do
