@@ -65,21 +65,33 @@ __device__ inline SearchConst search_const(const MapView &m) {
 // above any fp32 rounding of the offsets.  When a nearest neighbour inside the limit exists its voxel
 // is always scanned, so results are unchanged; only the work is.
 // SHARD_CHECK = false: the caller knows the map is not sharded (saves the scalar registers of the test)
-template <bool SHARD_CHECK = true>
-__device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &sc, D3 w, int lane, float reach) {
+// HALF: TWO queries at once, one per half of the wavefront - lanes 0..31 carry one query point in `w`, lanes
+// 32..63 another - through the same instruction stream: 27 probing lanes and 32 candidates per round for each.  A
+// wave with two queries then pays for little more than one (the cost of a query is the length of this chain of
+// dependent steps, not the lanes it keeps busy) where two passes cost two.  Every cross-lane step stays inside its
+// half; the result is per lane (uniform within a half) and equals what the query gets on a whole wave.
+template <bool SHARD_CHECK = true, bool HALF = false>
+__device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &sc, D3 w, int wlane, float reach) {
+    constexpr int W = HALF ? 32 : 64;             // lanes per query
+    const int lane = HALF ? (wlane & 31) : wlane;  // lane within the query's group
+    const int hb = HALF ? (wlane & 32) : 0;        // first lane of the group
     const K3 kc{voxel_coord_fast(w.x, m.voxel, sc.inv_voxel), voxel_coord_fast(w.y, m.voxel, sc.inv_voxel),
                 voxel_coord_fast(w.z, m.voxel, sc.inv_voxel)};
+    bool answer = true;
     if (SHARD_CHECK && m.shard_world > 1 && shard_owner(kc, m.shard_log2, m.shard_world) != m.shard_rank) {
         // sharded map: the rank that owns the centre voxel answers this query (it holds all 27 neighbours)
-        QueryResult none;
-        none.found = false; none.target = D3{0, 0, 0}; none.label = 0; none.candidates = 0; none.probes = 0;
-        return none;
+        if (!HALF) {
+            QueryResult none;
+            none.found = false; none.target = D3{0, 0, 0}; none.label = 0; none.candidates = 0; none.probes = 0;
+            return none;
+        }
+        answer = false;  // the other half may have a query of this rank: walk along with nothing to look at
     }
     int slot = -1;
     uint32_t cnt = 0;
     int probes = 0;
     float relx = 0.f, rely = 0.f, relz = 0.f;
-    if (lane < 27) {
+    if (lane < 27 && answer) {
         const K3 kn{kc.x + lane / 9 - 1, kc.y + (lane / 3) % 3 - 1, kc.z + lane % 3 - 1};
         // the query in this voxel's frame (voxel origin = key * voxel_size), rounded to fp32 once
         relx = (float)(w.x - (double)kn.x * m.voxel);
@@ -109,11 +121,12 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
         }
     }
     const bool occ = slot >= 0 && cnt > 0;
-    const unsigned long long occmask = __ballot(occ);
+    const unsigned long long ballot = __ballot(occ);
+    const unsigned long long occmask = HALF ? ((ballot >> hb) & 0xFFFFFFFFull) : ballot;
     const int nf = __popcll(occmask);
-    // stable partition of the lanes: occupied voxels first, in visiting order
+    // stable partition of the group's lanes: occupied voxels first, in visiting order
     const int before = __popcll(occmask & ((1ull << lane) - 1ull));
-    const int dst = (occ ? before : nf + (lane - before)) << 2;
+    const int dst = (hb + (occ ? before : nf + (lane - before))) << 2;
     const int c_slot = __builtin_amdgcn_ds_permute(dst, slot);
     const int c_meta = __builtin_amdgcn_ds_permute(dst, (int)(cnt | ((uint32_t)lane << 8)));
     const float c_relx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(relx)));
@@ -137,10 +150,10 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     auto fetch = [&](int c0, Chunk &ch) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
-            const int c = c0 + r * 64 + lane;
+            const int c = c0 + r * W + lane;
             const int k = (int)__umulhi((uint32_t)c, sc.cap_magic);
             const int p = c - k * m.cap;
-            const int kk = (k < nf ? k : 0) << 2;
+            const int kk = (hb + (k < nf ? k : 0)) << 2;
             const int es = __builtin_amdgcn_ds_bpermute(kk, c_slot);
             const int em = __builtin_amdgcn_ds_bpermute(kk, c_meta);
             ch.rx[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_relx)));
@@ -166,10 +179,10 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
             ++ncand;
         }
     };
-    if (total > 0) {
+    if (total > 0) {  // HALF: per group, the groups leave the loop one after the other
         Chunk cur, nxt;
         fetch(0, cur);
-        for (int c0 = 64 * kRounds; c0 < total; c0 += 64 * kRounds) {
+        for (int c0 = W * kRounds; c0 < total; c0 += W * kRounds) {
             fetch(c0, nxt);
             score(cur);
             cur = nxt;
@@ -178,12 +191,12 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     }
     unsigned long long wbest = best;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = W / 2; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(wbest, o);
         wbest = other < wbest ? other : wbest;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = W / 2; o > 0; o >>= 1) {
         ncand += __shfl_xor(ncand, o);
         probes += __shfl_xor(probes, o);
     }
@@ -193,8 +206,9 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     r.found = wbest != ~0ull;
     r.label = 0;
     r.target = D3{0, 0, 0};
+    const unsigned long long winners = __ballot(best == wbest);
     if (r.found) {
-        const int winner = __ffsll((long long)__ballot(best == wbest)) - 1;
+        const int winner = hb + __ffsll((long long)(HALF ? ((winners >> hb) & 0xFFFFFFFFull) : winners)) - 1;
         const float fx = __shfl(bx, winner), fy = __shfl(by, winner), fz = __shfl(bz, winner);
         r.label = __shfl(blabel, winner);
         const int v = (int)__umulhi((uint32_t)(wbest & 0xFFFFFFFFull), sc.cap_magic);
@@ -450,48 +464,37 @@ __device__ inline void solve_and_update(DevState *st, const TailState &ts, const
     }
 }
 
-// One Gauss-Newton iteration.  Every block reduces its queries to kIcpSums partial sums; with
-// fuse != 0 the block that publishes LAST (ticket counter in DevState) folds all partials in fixed
-// order and runs the solve, so an iteration is a single dispatch.  The fold order does not depend on
-// which block happens to be last, so results stay bit-reproducible.
-// Cross-block visibility: the partials are written and read with agent-scope atomics (they bypass
-// the per-XCD L2), and wave 0 - which issues both the partial stores and the ticket increment -
-// orders them with the increment's release.  A __threadfence() by all 512 threads here measured
-// +29 us per launch.
-__global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, CloudView src, int src_cap,
-                                                                    const int32_t *__restrict__ n_ptr, DevState *st,
-                                                                    double *partials, int fuse, HostMirror *mirror) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int waves_per_block = kIcpThreads / 64;
-    // the first query's coordinates are fetched before anything is known about the state (the arrays
-    // hold src_cap elements whatever n is), so this load overlaps the state loads
-    int q = blockIdx.x * waves_per_block + wave;
-    const int qs = q < src_cap ? q : src_cap - 1;
-    D3 p{src.x[qs], src.y[qs], src.z[qs]};
-    int label = src.l[qs];
-    if (st->icp_done) return;
-    const int n = *n_ptr;
-    const Rigid T = st->T_total;
-    const double max_corr = st->max_corr, th = st->kernel_th;
-    const SearchConst sc = search_const(m);
-    const double max_corr2 = max_corr * max_corr, th2 = th * th;
-    const bool plain = th < 0.0;  // no robust kernel, no class weight (loopclosure/FastIcp.cpp:146-152)
-    const float reach = (float)max_corr + 1e-3f;
-    double acc[kIcpSums];
-#pragma unroll
-    for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
-    while (q < n) {
-        const D3 s = apply(T, p);
-        const int lab = label;
-        q += gridDim.x * waves_per_block;
-        if (q < n) {
-            p = D3{src.x[q], src.y[q], src.z[q]};
-            label = src.l[q];
+// ---- a wave's share of the queries of one Gauss-Newton iteration (both registration kernels) ----
+// The wave takes the queries q0, q0 + stride, ...: two at a time on its two halves while two or more are left
+// (wave_nearest<.., true>), a last one on the whole wave.  A lane keeps the books of the queries of its half; a
+// query worked on by the whole wave is booked by the lower half alone, so lane 0 and lane 32 end up with two
+// disjoint partial sums (lane 32's is zero for a wave that never had two queries).
+__device__ inline int icp_lane_query(int q, int stride, int n, int lane) { return (q + stride < n && lane >= 32) ? q + stride : q; }
+
+template <bool SHARD_CHECK>
+__device__ inline void accumulate_queries(const MapView &m, const SearchConst &sc, const CloudView &src, const int n, const int q0,
+                                          const int stride, const Rigid &T, const D3 p0, const int label0 /*of icp_lane_query(q0)*/,
+                                          const double max_corr2, const double th, const double th2, const bool plain,
+                                          const float reach, const int lane, double (&acc)[kIcpSums]) {
+    int q = q0;
+    int n_corr = 0, n_cand = 0, n_probe = 0;  // counts stay integers inside the loop (the kernel is short of registers)
+    for (int step = 0; q < n; ++step) {
+        const bool pair = q + stride < n;
+        D3 p = p0;
+        int lab = label0;
+        if (step > 0) {
+            const int ql = icp_lane_query(q, stride, n, lane);
+            p = D3{src.x[ql], src.y[ql], src.z[ql]};
+            lab = src.l[ql];
         }
-        const QueryResult r = wave_nearest(m, sc, s, lane, reach);
-        acc[17] += (double)r.candidates;
-        acc[18] += (double)r.probes;
+        const D3 s = apply(T, p);
+        QueryResult r;
+        if (pair) r = wave_nearest<SHARD_CHECK, true>(m, sc, s, lane, reach);
+        else r = wave_nearest<SHARD_CHECK, false>(m, sc, s, lane, reach);
+        q += pair ? 2 * stride : stride;
+        if (!pair && lane >= 32) continue;
+        n_cand += r.candidates;
+        n_probe += r.probes;
         if (!r.found) continue;
         const D3 res = sub(s, r.target);
         const double r2 = sq3(res);
@@ -507,15 +510,50 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
         acc[10] += ws * res.x; acc[11] += ws * res.y; acc[12] += ws * res.z;
         const D3 sxr = crs(s, res);
         acc[13] += ws * sxr.x; acc[14] += ws * sxr.y; acc[15] += ws * sxr.z;
-        acc[16] += 1.0;
+        ++n_corr;
     }
-    __shared__ double red[kIcpThreads / 64][kIcpSums];
+    acc[16] += (double)n_corr;
+    acc[17] += (double)n_cand;
+    acc[18] += (double)n_probe;
+}
+
+// One Gauss-Newton iteration.  Every block reduces its queries to kIcpSums partial sums; with
+// fuse != 0 the block that publishes LAST (ticket counter in DevState) folds all partials in fixed
+// order and runs the solve, so an iteration is a single dispatch.  The fold order does not depend on
+// which block happens to be last, so results stay bit-reproducible.
+// Cross-block visibility: the partials are written and read with agent-scope atomics (they bypass
+// the per-XCD L2), and wave 0 - which issues both the partial stores and the ticket increment -
+// orders them with the increment's release.  A __threadfence() by all 512 threads here measured
+// +29 us per launch.
+__global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, CloudView src, int src_cap,
+                                                                    const int32_t *__restrict__ n_ptr, DevState *st,
+                                                                    double *partials, int fuse, HostMirror *mirror) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int waves_per_block = kIcpThreads / 64;
+    if (st->icp_done) return;
+    const int n = *n_ptr;
+    const int q0 = blockIdx.x * waves_per_block + wave, stride = gridDim.x * waves_per_block;
+    const int ql = icp_lane_query(q0 < src_cap ? q0 : src_cap - 1, stride, n, lane);
+    const D3 p0{src.x[ql], src.y[ql], src.z[ql]};
+    const int label0 = src.l[ql];
+    const Rigid T = st->T_total;
+    const double max_corr = st->max_corr, th = st->kernel_th;
+    const SearchConst sc = search_const(m);
+    const double max_corr2 = max_corr * max_corr, th2 = th * th;
+    const bool plain = th < 0.0;  // no robust kernel, no class weight (loopclosure/FastIcp.cpp:146-152)
+    const float reach = (float)max_corr + 1e-3f;
+    double acc[kIcpSums];
+#pragma unroll
+    for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
+    accumulate_queries<true>(m, sc, src, n, q0, stride, T, p0, label0, max_corr2, th, th2, plain, reach, lane, acc);
+    __shared__ double red[kIcpThreads / 64][2][kIcpSums];
     __shared__ double S[kIcpSums];
     __shared__ double solve_x[6];
     __shared__ int is_last;
-    if (lane == 0) {
+    if ((lane & 31) == 0) {
 #pragma unroll
-        for (int k = 0; k < kIcpSums; ++k) red[wave][k] = acc[k];
+        for (int k = 0; k < kIcpSums; ++k) red[wave][lane >> 5][k] = acc[k];
     }
     __syncthreads();
     if (wave != 0) {
@@ -524,7 +562,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
         if (lane < kIcpSums) {
             double sum = 0.0;
 #pragma unroll
-            for (int w = 0; w < kIcpThreads / 64; ++w) sum += red[w][lane];
+            for (int w = 0; w < kIcpThreads / 64; ++w) sum += red[w][0][lane] + red[w][1][lane];
             // [scalar][block]: the fold reads rows
             __hip_atomic_store(&partials[(size_t)lane * gridDim.x + blockIdx.x], sum, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -568,8 +606,11 @@ __device__ uint32_t g_icp_dbg[kDbgIters * kIcpBlocks * 8];
 #endif
 constexpr uint32_t kSpinLimit = 1u << 21;
 
+#ifndef SGS_ICP_MIN_WAVES
+#define SGS_ICP_MIN_WAVES 2  // per SIMD: two blocks must fit a CU, or the blocks queue behind the clustering kernel's CUs
+#endif
 template <bool SHARDED>
-__global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, CloudView src, int src_cap,
+__global__ __launch_bounds__(kIcpThreads, SGS_ICP_MIN_WAVES) void icp_persistent_kernel(MapView m, CloudView src, int src_cap,
                                                                      const int32_t *__restrict__ n_ptr, DevState *st,
                                                                      double *partials2 /*two [kIcpSums][kIcpBlocks] buffers*/,
                                                                      uint32_t *tickets /*kIcpTickets counters, 128 B apart, zero*/,
@@ -577,11 +618,12 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int waves_per_block = kIcpThreads / 64;
-    const int q0 = blockIdx.x * waves_per_block + wave;
-    const int qs = q0 < src_cap ? q0 : src_cap - 1;
-    const D3 p0{src.x[qs], src.y[qs], src.z[qs]};  // the wave's first (usually only) query stays in registers
-    const int label0 = src.l[qs];
+    const int q0 = blockIdx.x * waves_per_block + wave, stride = gridDim.x * waves_per_block;
     const int n = *n_ptr;
+    // the wave's first query - or first two, one per half of the wave - stays in registers for the whole loop
+    const int ql = icp_lane_query(q0 < src_cap ? q0 : src_cap - 1, stride, n, lane);
+    const D3 p0{src.x[ql], src.y[ql], src.z[ql]};
+    const int label0 = src.l[ql];
     if (mirror && blockIdx.x == 0 && threadIdx.x == 0) mirror->t_icp_start = wall_clock64();
     // the registration state: left in DevState by icp_init_kernel, or - a launch chained behind a map update, with
     // no dispatch in between - written into the host mirror by the host
@@ -610,7 +652,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
     const double max_corr2 = max_corr * max_corr, th2 = th * th;
     const bool plain = th < 0.0;  // no robust kernel, no class weight (loopclosure/FastIcp.cpp:146-152)
     const float reach = (float)max_corr + 1e-3f;
-    __shared__ double red[kIcpThreads / 64][kIcpSums];
+    __shared__ double red[kIcpThreads / 64][2][kIcpSums];
     __shared__ double S[kIcpSums];
     __shared__ double solve_x[6];
     // state only thread 0 / the solving lanes need stays in LDS: the kernel is short of scalar registers
@@ -628,38 +670,10 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
         double acc[kIcpSums];
 #pragma unroll
         for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
-        D3 p = p0;
-        int label = label0;
-        int q = q0;
-        while (q < n) {
-            const D3 s = apply(T_total, p);
-            const int lab = label;
-            q += gridDim.x * waves_per_block;
-            if (q < n) {
-                p = D3{src.x[q], src.y[q], src.z[q]};
-                label = src.l[q];
-            }
-            const QueryResult r = wave_nearest<SHARDED>(m, sc, s, lane, reach);
-            acc[17] += (double)r.candidates;
-            acc[18] += (double)r.probes;
-            if (!r.found) continue;
-            const D3 res = sub(s, r.target);
-            const double r2 = sq3(res);
-            if (!(r2 < max_corr2)) continue;
-            const double wgt = plain ? 1.0 : th2 / ((th + r2) * (th + r2));
-            const double ws = plain ? 1.0 : wgt * semantic_weight(lab);
-            acc[0] += wgt;
-            acc[1] += wgt * s.x; acc[2] += wgt * s.y; acc[3] += wgt * s.z;
-            acc[4] += wgt * s.x * s.x; acc[5] += wgt * s.y * s.y; acc[6] += wgt * s.z * s.z;
-            acc[7] += wgt * s.x * s.y; acc[8] += wgt * s.x * s.z; acc[9] += wgt * s.y * s.z;
-            acc[10] += ws * res.x; acc[11] += ws * res.y; acc[12] += ws * res.z;
-            const D3 sxr = crs(s, res);
-            acc[13] += ws * sxr.x; acc[14] += ws * sxr.y; acc[15] += ws * sxr.z;
-            acc[16] += 1.0;
-        }
-        if (lane == 0) {
+        accumulate_queries<SHARDED>(m, sc, src, n, q0, stride, T_total, p0, label0, max_corr2, th, th2, plain, reach, lane, acc);
+        if ((lane & 31) == 0) {
 #pragma unroll
-            for (int k = 0; k < kIcpSums; ++k) red[wave][k] = acc[k];
+            for (int k = 0; k < kIcpSums; ++k) red[wave][lane >> 5][k] = acc[k];
         }
         __syncthreads();
         SGS_STAMP(ts1);
@@ -669,7 +683,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persistent_kernel(MapView m, 
             if (lane < kIcpSums) {
                 double sum = 0.0;
 #pragma unroll
-                for (int w = 0; w < kIcpThreads / 64; ++w) sum += red[w][lane];
+                for (int w = 0; w < kIcpThreads / 64; ++w) sum += red[w][0][lane] + red[w][1][lane];
                 __hip_atomic_store(&buf[(size_t)lane * gridDim.x + blockIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the arrival
