@@ -272,6 +272,27 @@ def test_linear_system_matches_oracle():
     ctx.close()
 
 
+@pytest.mark.parametrize("nq", [1000, 1024, 1025, 1500, 2048, 2049, 3000, 4500])
+def test_linear_system_with_two_queries_per_wavefront(nq):
+    """More than 1024 queries: a wavefront takes two at a time, one per half (wave_nearest<.., HALF>), then a last one
+    on the whole wave.  Counts on both sides of every switch; the sums must be the oracle's whatever the split."""
+    ctx, om = _filled(shape="hdl64", frames=(0, 1, 2, 3))
+    _, xyz, lab = _scan(4, "hdl64")
+    px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
+    dx, dl, _, _ = O.voxel_downsample(px, pl, 0.5)
+    assert len(dx) >= nq
+    guess = O.se3_mul(synth.gt_pose(4), O.se3_exp([0.2, 0.05, 0, 0, 0, 0.01]))
+    q = _xyzl(O.se3_act(guess, dx[:nq]), dl[:nq])
+    lo, no = om.build_linear_system(q, 6.0, 0.667)
+    lg, ng = ctx.BuildLinearSystem(q, 6.0, 0.667)
+    assert no == ng and no > nq // 2
+    assert np.max(np.abs(lo - lg)) / np.abs(lo).max() < 1e-6
+    so, to, qo, _ = om.get_correspondences(q, 1.0)
+    sg, tg, qg = ctx.GetCorrespondences(q, 1.0)
+    assert abs(len(qo) - len(qg)) <= 2
+    ctx.close()
+
+
 def test_register_frame_matches_oracle():
     ctx, om = _filled()
     sx, sl = _source(3)
@@ -655,6 +676,24 @@ def test_icp_one_launch_loop_matches_launch_per_iteration():
         assert np.array_equal(ra["pose"], rb["pose"]), (k, ra["pose"] - rb["pose"])
         assert ra["correspondences"] == rb["correspondences"] and ra["candidates"] == rb["candidates"]
     assert a.stats().icp_fallbacks == 0
+    a.close()
+    b.close()
+    # a shape with more than 1024 sources per scan: wavefronts with two queries in both kernels
+    a = make_ctx(max_points=1 << 17)
+    os.environ["SGS_ICP_PER_LAUNCH"] = "1"
+    try:
+        b = make_ctx(max_points=1 << 17)
+    finally:
+        del os.environ["SGS_ICP_PER_LAUNCH"]
+    most = 0
+    for k in range(6):
+        xyzi, xyz, lab = _scan(k, "os1_64")
+        ra, rb = a.process_scan_f32(xyzi, lab, None, ""), b.process_scan_f32(xyzi, lab, None, "")
+        assert ra["iterations"] == rb["iterations"], k
+        assert np.array_equal(ra["pose"], rb["pose"]), (k, ra["pose"] - rb["pose"])
+        assert ra["correspondences"] == rb["correspondences"] and ra["candidates"] == rb["candidates"]
+        most = max(most, ra["n_src"])
+    assert most > 1024
     a.close()
     b.close()
 
