@@ -392,6 +392,52 @@ def test_key_sharded_map_registers_like_one_map(world, block_log2):
         c.close()
 
 
+def test_key_sharded_registration_with_two_queries_per_wavefront():
+    """Three ranks, 3 000 sources: every wavefront takes two queries at a time, and in a pair one query may be this
+    rank's and the other not (that half walks along with nothing to look at)."""
+    import threading
+    world = 3
+    ctxs = [make_ctx() for _ in range(world)]
+    om = O.Map(1.0, 100.0, 20)
+    ar = _ThreadAllReduce(world)
+    for r, c in enumerate(ctxs):
+        c.ShardSet(r, world, 2, ar(r))
+    for k in (0, 1, 2, 3):
+        _, xyz, lab = _scan(k, "hdl64")
+        px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
+        dx, dl, _, _ = O.voxel_downsample(px, pl, 0.5)
+        om.update(_xyzl(dx, dl), synth.gt_pose(k))
+        for c in ctxs:
+            c.Update(_xyzl(dx, dl), synth.gt_pose(k))
+    _, xyz, lab = _scan(4, "hdl64")
+    px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
+    dx, dl, _, _ = O.voxel_downsample(px, pl, 0.5)
+    q = _xyzl(dx[:3000], dl[:3000])
+    guess = O.se3_mul(synth.gt_pose(4), O.se3_exp([0.2, 0.05, 0.0, 0, 0, 0.01]))
+    po_, info = om.register_frame(q, guess, 6.0, 0.667)
+    out = [None] * world
+
+    def run(r):
+        try:
+            out[r] = ctxs[r].RegisterFrameSemantic(q, guess, 6.0, 0.667)
+        except BaseException as e:  # noqa: BLE001
+            out[r] = e
+            ar.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    for o in out:
+        assert not isinstance(o, BaseException), repr(o)
+    for pg, itg in out:
+        assert np.array_equal(pg, out[0][0]) and itg == out[0][1]
+    et, er = pose_err(po_, out[0][0])
+    assert et < 1e-6 and er < 1e-7
+    assert abs(out[0][1] - info["iterations"]) <= 1
+    for c in ctxs:
+        c.close()
+
+
 def test_key_sharded_pipeline_matches_unsharded_pipeline():
     """sgs_process_scan on two ranks that share one map by key: same poses as one context with the whole map."""
     import threading
