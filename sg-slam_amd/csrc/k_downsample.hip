@@ -8,7 +8,8 @@
 // The reference grid has B = pow2ceil(2n) buckets (reserve(n), max load 0.5) and iterates them in
 // ascending bucket index.  Robin-hood and plain linear probing occupy the SAME set of buckets, and
 // everything that ever happens to an element stays inside its maximal run of occupied buckets.  So:
-//   1 clear     B-slot scratch table
+//   1 (clear)   the B-slot scratch table is empty on entry: cleared once when it is allocated, and step 4 leaves
+//               every bucket it has consumed empty again (a launch less per grid)
 //   2 insert    plain linear probing from the reference's home bucket (hash & (B-1)), atomicCAS on the
 //               packed integer key + atomicMin of the input index  -> occupied set + each voxel's
 //               first index (= its insertion time in the reference)
@@ -42,23 +43,18 @@ __device__ inline uint32_t buckets_for(int n) {  // pow2ceil(ceil(n / 0.5))
     return b;
 }
 
-__global__ __launch_bounds__(kBlock) void ds_clear_kernel(DsJobs jobs) {
-    const DsJob &J = jobs.j[blockIdx.y];
-    const int n = *J.n_in;
-    if (n <= 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *J.n_out = 0;
-        return;
-    }
-    const uint32_t B = buckets_for(n);
-    ulonglong2 *t = reinterpret_cast<ulonglong2 *>(J.table);
-    const ulonglong2 empty = make_ulonglong2(kEmptyKey, 0x00000000FFFFFFFFull);  // minidx = UINT_MAX
-    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < B; s += gridDim.x * kBlock) t[s] = empty;
+__device__ inline ulonglong2 ds_empty_entry() { return make_ulonglong2(kEmptyKey, 0x00000000FFFFFFFFull); }  // minidx = UINT_MAX
+
+__global__ __launch_bounds__(kBlock) void ds_clear_kernel(DsEntry *table, uint32_t B) {
+    ulonglong2 *t = reinterpret_cast<ulonglong2 *>(table);
+    for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < B; s += gridDim.x * kBlock) t[s] = ds_empty_entry();
 }
 
 __global__ __launch_bounds__(kBlock) void ds_insert_kernel(DsJobs jobs, DevState *st) {
     const DsJob &J = jobs.j[blockIdx.y];
     const int n = *J.n_in;
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (n <= 0 && i == 0) *J.n_out = 0;  // the later stages do nothing for an empty input
     if (i >= n) return;
     const uint32_t mask = buckets_for(n) - 1u;
     const K3 k = voxel_of(J.in.x[i], J.in.y[i], J.in.z[i], J.voxel);
@@ -196,9 +192,11 @@ __global__ __launch_bounds__(kBlock) void ds_replay_kernel(DsJobs jobs) {
             if (++u >= L) break;  // cannot happen (the run has exactly L buckets); guards against a hang
         }
     }
+    ulonglong2 *t = reinterpret_cast<ulonglong2 *>(J.table);
     for (uint32_t u = 0; u < L; ++u) {
         const uint32_t s = (s0 + u) & mask;
         J.order[J.homebase[s]] = lay[s].y;
+        t[s] = ds_empty_entry();  // nothing reads the table after this stage: leave it empty for the next scan
     }
 }
 
@@ -227,14 +225,16 @@ void launch_downsample(hipStream_t s, const DsJob *jobs, int njobs, int n_upper,
     const int nb_pts = (n_upper + kBlock - 1) / kBlock;
     const int nb_scan = (int)((Bmax + kScanTile - 1) / kScanTile);
     const int nb_slots = (int)((Bmax + kBlock - 1) / kBlock);
-    const int nb_clear = nb_scan < 1024 ? nb_scan : 1024;
     const dim3 blk(kBlock);
-    hipLaunchKernelGGL(ds_clear_kernel, dim3(nb_clear, njobs), blk, 0, s, js);
     hipLaunchKernelGGL(ds_insert_kernel, dim3(nb_pts, njobs), blk, 0, s, js, st);
     hipLaunchKernelGGL(ds_scan_a_kernel, dim3(nb_scan, njobs), blk, 0, s, js);
     hipLaunchKernelGGL(ds_scan_b_kernel, dim3(nb_scan, njobs), blk, 0, s, js);
     hipLaunchKernelGGL(ds_replay_kernel, dim3(nb_slots, njobs), blk, 0, s, js);
     hipLaunchKernelGGL(ds_gather_kernel, dim3(nb_pts, njobs), blk, 0, s, js);
+}
+
+void launch_downsample_table_clear(hipStream_t s, DsEntry *table, size_t entries) {
+    hipLaunchKernelGGL(ds_clear_kernel, dim3(1024), dim3(kBlock), 0, s, table, (uint32_t)entries);
 }
 
 }  // namespace sgs

@@ -1123,6 +1123,7 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     while (Bmax < 2 * N) Bmax <<= 1;
     for (int k = 0; k < 2; ++k) {
         if ((r = dev_alloc(c, &c->ds_table[k], Bmax))) return bail(r);
+        launch_downsample_table_clear(c->stream, c->ds_table[k], Bmax);  // every downsample leaves it empty again (synchronised below)
         if ((r = dev_alloc(c, &c->ds_homebase[k], Bmax))) return bail(r);
         if ((r = dev_alloc(c, &c->ds_blocksum[k], Bmax / 1024 + 2))) return bail(r);
         if ((r = dev_alloc(c, &c->ds_sim[k], Bmax * 2))) return bail(r);

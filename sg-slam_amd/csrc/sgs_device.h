@@ -128,7 +128,10 @@ void launch_preprocess(hipStream_t s, const float *in_f32, const double *in_f64,
 void launch_voxel_keys(hipStream_t s, const double *xyz, int n, double voxel, int32_t *keys);
 
 // ---- k_downsample.hip ----
+// the jobs' scratch tables must be empty on entry (launch_downsample_table_clear once after allocation) and are
+// left empty again
 void launch_downsample(hipStream_t s, const DsJob *jobs, int njobs, int n_upper, DevState *st);
+void launch_downsample_table_clear(hipStream_t s, DsEntry *table, size_t entries);
 
 // ---- k_map.hip ----
 void launch_map_init(hipStream_t s, MapView m);
