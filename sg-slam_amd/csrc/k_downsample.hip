@@ -60,6 +60,20 @@ __global__ __launch_bounds__(kBlock) void ds_insert_kernel(DsJobs jobs, DevState
     const K3 k = voxel_of(J.in.x[i], J.in.y[i], J.in.z[i], J.voxel);
     if (!key_in_range(k)) atomicOr(&st->err_flags, ERR_KEY_RANGE);
     const unsigned long long pk = pack_key(k);
+    // Neighbours in the scan mostly fall into the same voxel.  A lane whose key one of the few lanes below it
+    // also holds leaves the work to that lane (same wave, lower index, same key - and so on down to a lane that
+    // is not covered): the table ends up the same with a fraction of the probes and atomics, which are resolved
+    // memory-side and slow down everything else that runs on the chip meanwhile.
+    {
+        const int lane = threadIdx.x & 63;
+        bool covered = false;
+#pragma unroll
+        for (int d = 1; d <= 4; ++d) {
+            const unsigned long long below = __shfl_up(pk, d);
+            covered = covered || (lane >= d && below == pk);
+        }
+        if (covered) return;
+    }
     uint32_t s = ref_hash(k) & mask;
     while (true) {
         // plain read first: a stale EMPTY only costs the CAS below; a non-EMPTY value is final
