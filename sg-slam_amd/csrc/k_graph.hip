@@ -304,7 +304,7 @@ struct ClusterMem {
     int32_t *tkey;    // [cap] cell table: voxel_index, INT_MIN = empty
     int32_t *tmin;    // [cap] smallest point index in the cell
     int32_t *tlab;    // [cap] a label value of the cell's cluster, -1 = none yet
-    int32_t *tswept;  // [cap] 1 = every point of the cell is labelled, 2 = cell outside every neighbour list
+    int32_t *tswept;  // [cap] 1 = every point of the cell is labelled, 2 = cell outside every neighbour list, 3 = and its own list is empty
     int32_t *tpol, *trng, *tazi;  // [cap] cell coordinates
     int32_t *tcidx;   // [cap] dense index of the occupied cell (neighbour-list row)
     int32_t *nbr;     // [nbr_cells][27] slots of the neighbour cells in visiting order, -1 = none; may be null
@@ -394,6 +394,13 @@ __device__ __forceinline__ bool cluster_class_body(const int c, const int n, con
             const int ci = e / 27, k = e - 27 * ci;
             M.nbr[e] = neighbour_slot(M, M.plabel[ci], k, length, width, height);
         }
+        __syncthreads();
+        // a cell whose whole neighbour list is empty (tswept = 3): see the walk
+        for (int ci = tid; ci < s_ncells; ci += kCluThreads) {
+            bool any = false;
+            for (int k = 0; k < 27; ++k) any = any || M.nbr[27 * ci + k] >= 0;
+            if (!any) M.tswept[M.plabel[ci]] = 3;
+        }
     }
     __syncthreads();
 
@@ -407,11 +414,33 @@ __device__ __forceinline__ bool cluster_class_body(const int c, const int n, con
             const int jj = base + lane;
             const int sl = jj < n ? cslot[jj] : 0;
             const int row = lists ? 27 * M.tcidx[sl] : 0;
+            const bool lonely = jj < n && M.tswept[sl] == 3;  // its cell sees no cell at all, not even itself
             while (true) {
                 const bool unl = jj < n && jj > last && M.tswept[sl] != 1;
                 const unsigned long long um = __ballot(unl);
                 if (!um) break;
                 const int fl0 = __ffsll((long long)um) - 1;
+                // A cell well outside the elevation window is in no neighbour list and has an empty one itself: its
+                // points are never swept, every one of them is a seed that finds nobody around and starts a cluster
+                // of its own.  A run of them - up to the next unlabelled point of any other cell, which may have to
+                // start a cluster itself - takes consecutive label values in index order: one step for the whole
+                // run (sensors that look above the reference's +2 degree window have hundreds per scan).
+                const unsigned long long om = __ballot(unl && lonely);
+                if ((om >> fl0) & 1ull) {
+                    const unsigned long long from = ~0ull << fl0;
+                    const unsigned long long regular = um & ~om & from;
+                    const unsigned long long upto = regular ? ((1ull << (__ffsll((long long)regular) - 1)) - 1ull) : ~0ull;
+                    const unsigned long long batch = om & from & upto;
+                    if ((batch >> lane) & 1ull) {
+                        const int lab = current + 1 + __popcll(batch & ((1ull << lane) - 1ull));
+                        parent[lab] = lab;
+                        M.plabel[jj] = lab;
+                    }
+                    current += __popcll(batch);
+                    last = base + 63 - __builtin_clzll(batch);
+                    wave_sync();
+                    continue;
+                }
                 const int i = base + fl0;  // next unlabelled point = seed
                 last = i;
                 const int own = __builtin_amdgcn_readlane(sl, fl0);
@@ -483,7 +512,7 @@ __device__ __forceinline__ bool cluster_class_body(const int c, const int n, con
     __syncthreads();
     for (int j = tid; j < n; j += kCluThreads) {
         const int sl = cslot[j];
-        const int v = find_root(parent, M.tswept[sl] == 2 ? M.plabel[j] : M.tlab[sl]);
+        const int v = find_root(parent, M.tswept[sl] >= 2 ? M.plabel[j] : M.tlab[sl]);
         const int oi = order[j];
         pt_cluster[oi] = v;
         ClusterStat *e = acc + v;
