@@ -293,6 +293,27 @@ def test_linear_system_with_two_queries_per_wavefront(nq):
     ctx.close()
 
 
+def test_linear_system_is_additive_at_full_size():
+    """Size-independent property: the 27 scalars are sums over the queries, so the system of a set of queries is the
+    sum of the systems of its parts (to fp64 rounding: only the order of the additions differs) - whichever wavefront
+    or half-wavefront a query lands on."""
+    ctx, om = _filled(shape="hdl64", frames=(0, 1, 2, 3))
+    _, xyz, lab = _scan(4, "hdl64")
+    px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
+    dx, dl, _, _ = O.voxel_downsample(px, pl, 0.5)
+    guess = O.se3_mul(synth.gt_pose(4), O.se3_exp([0.1, -0.05, 0, 0, 0, 0.005]))
+    q = _xyzl(O.se3_act(guess, dx), dl)
+    n = len(q)
+    assert n > 4096
+    whole, nw = ctx.BuildLinearSystem(q, 6.0, 0.667)
+    for cut in (1, 1000, 1024, n // 2, n - 1500):
+        a, na = ctx.BuildLinearSystem(q[:cut], 6.0, 0.667)
+        b, nb = ctx.BuildLinearSystem(q[cut:], 6.0, 0.667)
+        assert na + nb == nw
+        assert np.max(np.abs(a + b - whole)) <= 1e-11 * np.abs(whole).max()
+    ctx.close()
+
+
 def test_register_frame_matches_oracle():
     ctx, om = _filled()
     sx, sl = _source(3)
