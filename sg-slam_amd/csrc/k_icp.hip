@@ -142,9 +142,9 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     int ncand = 0;
     const int total = nf * m.cap;
     constexpr int kRounds = 3;
-    struct Chunk {
+    struct Chunk {  // kept small: two of them are live across the loads, and the kernel is short of registers
         float4 q[kRounds];
-        float rx[kRounds], ry[kRounds], rz[kRounds];
+        int kk[kRounds];   // byte address (bpermute) of the lane that holds the candidate's voxel
         int ord[kRounds];  // visiting ordinal v*cap + p of the candidate, -1 = none
     };
     auto fetch = [&](int c0, Chunk &ch) {
@@ -156,9 +156,7 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
             const int kk = (hb + (k < nf ? k : 0)) << 2;
             const int es = __builtin_amdgcn_ds_bpermute(kk, c_slot);
             const int em = __builtin_amdgcn_ds_bpermute(kk, c_meta);
-            ch.rx[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_relx)));
-            ch.ry[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_rely)));
-            ch.rz[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(kk, __float_as_int(c_relz)));
+            ch.kk[r] = kk;
             const bool valid = k < nf && p < (em & 0xFF);
             ch.ord[r] = valid ? (em >> 8) * m.cap + p : -1;
             if (valid) ch.q[r] = m.pts[(size_t)es * m.cap + p];
@@ -167,8 +165,12 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     auto score = [&](const Chunk &ch) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
+            // the query in the candidate's voxel frame, from that voxel's lane (nothing here waits for the loads)
+            const float rx = __int_as_float(__builtin_amdgcn_ds_bpermute(ch.kk[r], __float_as_int(c_relx)));
+            const float ry = __int_as_float(__builtin_amdgcn_ds_bpermute(ch.kk[r], __float_as_int(c_rely)));
+            const float rz = __int_as_float(__builtin_amdgcn_ds_bpermute(ch.kk[r], __float_as_int(c_relz)));
             if (ch.ord[r] < 0) continue;
-            const float dx = ch.q[r].x - ch.rx[r], dy = ch.q[r].y - ch.ry[r], dz = ch.q[r].z - ch.rz[r];
+            const float dx = ch.q[r].x - rx, dy = ch.q[r].y - ry, dz = ch.q[r].z - rz;
             const float d2 = dx * dx + (dy * dy + dz * dz);
             const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)ch.ord[r];
             if (key < best) {
