@@ -3,7 +3,8 @@
 // test of RegisterFrameSemantic (F/Registration.cpp:111-112,147-177) in a one-block kernel, so a whole
 // Gauss-Newton loop runs without a host round trip.
 //
-// Mapping: ONE WAVEFRONT PER QUERY (grid-stride over queries).  Lanes 0..26 probe the 27 neighbour
+// Mapping: ONE WAVEFRONT PER QUERY (grid-stride over queries; a wave that has two queries left works on both at
+// once, one per half of the wavefront - see wave_nearest<.., HALF> and accumulate_queries).  Lanes 0..26 probe the 27 neighbour
 // voxels in the reference's x-outer / z-inner order (one 16-B slot-header load per probe gives key +
 // count).  The occupied voxels are compacted across the wave with ds_permute (cross-lane through the
 // LDS crossbar, no LDS allocation), and their points - voxel-local fp32 (x,y,z,label) records stored
