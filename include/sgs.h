@@ -51,7 +51,7 @@ typedef struct sgs_config {
     double model_deviation_rot;
     double inlier_rate_th;
     int32_t deskew;
-    int32_t relocalization_enable; /* accepted, ignored: SURVEY.md row f1 (next) */
+    int32_t relocalization_enable; /* 1: instance tracking + relocalization in sgs_process_scan* (SemGraphSLAM.cpp:54,81-107,116); serial mode */
     double deltaA;
     double deltaR;
     double deltaP;

@@ -160,15 +160,17 @@ __global__ __launch_bounds__(kBlock) void map_prune_kernel(MapView m, const Rigi
                                           red[2][0] + red[2][1] + red[2][2] + red[2][3], 0);
 }
 
-__global__ __launch_bounds__(kBlock) void map_census_kernel(const int4 *__restrict__ blockstat, int nblocks, DevState *st,
-                                                            HostMirror *mirror, const int32_t *__restrict__ skip) {
+constexpr int kCensusBlock = 1024;  // one workgroup folds all per-block numbers: wide, so that the loads of a large map's sweep are few rounds
+__global__ __launch_bounds__(kCensusBlock) void map_census_kernel(const int4 *__restrict__ blockstat, int nblocks, DevState *st,
+                                                                  HostMirror *mirror, const int32_t *__restrict__ skip) {
     if (skip && *skip) return;
     int live = 0, tomb = 0, pts = 0;
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+#pragma unroll 4
+    for (int b = threadIdx.x; b < nblocks; b += kCensusBlock) {
         const int4 v = blockstat[b];
         live += v.x; tomb += v.y; pts += v.z;
     }
-    __shared__ int red[3][kBlock / 64];
+    __shared__ int red[3][kCensusBlock / 64];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         live += __shfl_down(live, o);
@@ -180,8 +182,11 @@ __global__ __launch_bounds__(kBlock) void map_census_kernel(const int4 *__restri
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int l = red[0][0] + red[0][1] + red[0][2] + red[0][3], t = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        const int p = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        int l = 0, t = 0, p = 0;
+#pragma unroll
+        for (int w = 0; w < kCensusBlock / 64; ++w) {
+            l += red[0][w]; t += red[1][w]; p += red[2][w];
+        }
         st->map_live = l;
         st->map_tomb = t;
         st->map_points = p;
@@ -246,7 +251,7 @@ void launch_map_sweep(hipStream_t s, MapView m, const Rigid *T_dev, const double
     const int nb = (int)((cap + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(map_prune_kernel, dim3(nb), dim3(kBlock), 0, s, m, T_dev, o, max_dist * max_dist, do_prune,
                        blockstat);
-    hipLaunchKernelGGL(map_census_kernel, dim3(1), dim3(kBlock), 0, s, blockstat, nb, st, mirror, m.skip);
+    hipLaunchKernelGGL(map_census_kernel, dim3(1), dim3(kCensusBlock), 0, s, blockstat, nb, st, mirror, m.skip);
 }
 
 void launch_map_rehash(hipStream_t s, MapView from, MapView to, DevState *st) {
