@@ -33,7 +33,8 @@ def main():
     ap.add_argument("--shape", default="hdl64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip instance clustering + graph (diagnostic only)")
-    ap.add_argument("--cpu-max-scans", type=int, default=120)
+    ap.add_argument("--cpu-max-scans", type=int, default=200,
+                    help="timed scans the CPU baseline (and the pose check against it) covers; default = all of the default --steps")
     ap.add_argument("--map-log2", type=int, default=19, help="initial voxel-map table size, log2 slots (grows by rehash)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not hand scan k+1 to sgs_prefetch_scan_f32_dev while scan k registers (default: do; the "
@@ -244,7 +245,7 @@ def main():
         O.set_threads(1)
         slam1 = O.Slam(O.kitti_config(enable_graph=0 if args.no_graph else 1))
         t1 = 0.0
-        m1 = min(10, m)
+        m1 = min(40, m)
         for i in range(W + m1):
             xyz = scans_host[i][:, :3].astype(np.float64)
             t0 = time.perf_counter()
