@@ -277,6 +277,27 @@ int sgs_get_poses(sgs_ctx *ctx, double *poses7, int cap, int *n);
 /* Loader helper (ros/ros1/InsUtils.hpp:50-85,526): SemanticKITTI raw label -> 0..25. */
 int sgs_remap_labels(const uint32_t *raw, int n, int32_t *out);
 
+/* ---- the one entry point that allocates nothing ----
+ * NO COUNTERPART IN THE REFERENCE.  It is for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  A variant of sgs_voxel_downsample (VoxelDownsampleSemantic,
+ * Preprocessing.cpp:70-94: first point per voxel, emitted in the reference's robin_map iteration order) that
+ * needs no context and calls no hipMalloc / hipFree / allocating routine: inputs and outputs are the caller's
+ * DEVICE buffers, and all the scratch the kernels need (SoA staging, bucket table, prefix + replay arrays) lives
+ * in one fixed device array inside the library (about 17.6 MB, held by every GPU the library runs on until the
+ * process ends), which limits a call to SGS_NOALLOC_MAX_POINTS points: a larger n returns SGS_ECAPACITY.
+ *   xyz_dev n*3 doubles, label_dev n int32; out_xyz_dev / out_label_dev / out_index_dev (each optional) receive the
+ *   first min(count, out_cap) emitted points; out_n2_dev = device int32[2]: [0] the full count, [1] error flags
+ *   (bit 0: a voxel key outside +-2^20).  hip_stream = a hipStream_t (NULL: the null stream); the work is only
+ *   ENQUEUED on it: the call does not synchronise, so it can be captured into a graph; the outputs are valid once
+ *   the stream has reached that point.  Runs on the CURRENT device.  All calls on one GPU share that GPU's
+ *   scratch array: calls that overlap on one GPU (two streams, two threads) race - serialise them.
+ * Errors: SGS_EINVAL / SGS_ECAPACITY / SGS_EHIP; sgs_last_error(NULL) returns the message of the calling thread's
+ * last failure here. */
+#define SGS_NOALLOC_MAX_POINTS 131072
+int sgs_voxel_downsample_dev_noalloc(const double *xyz_dev, const int32_t *label_dev, int n, double voxel_size,
+                                     double *out_xyz_dev, int32_t *out_label_dev, int32_t *out_index_dev, int out_cap,
+                                     int32_t *out_n2_dev, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

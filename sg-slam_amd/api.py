@@ -29,8 +29,9 @@ ABI_SYMBOLS = [
     "sgs_map_update", "sgs_map_prune", "sgs_map_size", "sgs_map_pointcloud", "sgs_map_dump",
     "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_shard_set", "sgs_fast_icp", "sgs_graph_map_clear", "sgs_graph_map_track", "sgs_graph_map_instances", "sgs_graph_map_relocalize", "sgs_find_ins_match", "sgs_solve_svd", "sgs_ransac_alignment", "sgs_scan_descriptor", "sgs_gen_scan_descriptor", "sgs_cluster_points",
     "sgs_build_graph", "sgs_process_scan", "sgs_process_scan_f32", "sgs_process_scan_f32_dev", "sgs_prefetch_scan_f32_dev", "sgs_get_cloud",
-    "sgs_get_boxes", "sgs_get_poses", "sgs_remap_labels",
+    "sgs_get_boxes", "sgs_get_poses", "sgs_remap_labels", "sgs_voxel_downsample_dev_noalloc",
 ]
+NOALLOC_MAX_POINTS = 131072  # SGS_NOALLOC_MAX_POINTS
 
 
 # int (*sgs_allreduce_fn)(double *buf, int count, void *user)
@@ -138,6 +139,7 @@ def lib():
         L.sgs_get_boxes.argtypes = [c_vp, c_vp, c_int, c_vp]
         L.sgs_get_poses.argtypes = [c_vp, c_vp, c_int, c_vp]
         L.sgs_remap_labels.argtypes = [c_vp, c_int, c_vp]
+        L.sgs_voxel_downsample_dev_noalloc.argtypes = [c_vp, c_vp, c_int, c_dbl, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]
         _LIB = L
     return _LIB
 

@@ -1081,6 +1081,7 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SGS_EHIP;
     if (hipSetDevice(device) != hipSuccess) return SGS_EHIP;
+    if (noalloc_setup_device(device) == SGS_EHIP) return SGS_EHIP;  // library set-up for this GPU: address of its fixed scratch array
     sgs_ctx *c = new sgs_ctx();
     c->cfg = cfg;
     c->device = device;
@@ -1206,7 +1207,7 @@ void sgs_destroy(sgs_ctx *c) {
     delete c;
 }
 
-const char *sgs_last_error(const sgs_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *sgs_last_error(const sgs_ctx *c) { return c ? c->err.c_str() : noalloc_last_error(); }  // NULL: the context-free entry point's
 
 int sgs_get_stats(sgs_ctx *c, sgs_stats *out) {
     if (bad_ctx(c) || !out) return SGS_EINVAL;

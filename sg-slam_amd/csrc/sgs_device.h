@@ -166,4 +166,9 @@ void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, doub
                             int32_t *found);
 void launch_linear_system_finish(hipStream_t s, DevState *st, double *partials, double *out27_dev);
 
+// ---- sgs_noalloc.hip ----
+// resolves the address of `device`'s copy of the fixed scratch array of sgs_voxel_downsample_dev_noalloc (once per device)
+int noalloc_setup_device(int device);
+const char *noalloc_last_error();
+
 }  // namespace sgs

@@ -1,0 +1,173 @@
+// sgs_voxel_downsample_dev_noalloc: VoxelDownsampleSemantic (F/Preprocessing.cpp:70-94) for callers that cannot
+// allocate - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels as
+// sgs_voxel_downsample (k_downsample.hip), but every byte of device memory beyond the caller's inputs and outputs
+// - the SoA staging of the cloud, the B-bucket scratch table, its prefix array, the two robin-hood replay arrays,
+// the emission order, the error word - lives in ONE file-scope device array of fixed size instead of a context's
+// hipMalloc'ed buffers.  No counterpart in the reference.
+//
+// The array's name is a host-side stand-in, not a device address: its address on a GPU is resolved ONCE per
+// device with hipGetSymbolAddress (noalloc_setup_device, called by sgs_create and by the entry point's first call
+// on a device) and only that pointer is ever handed to kernels, hipMemsetAsync or copies.  Every call on a GPU
+// shares that GPU's array: it is re-initialised where it has to start clean (the bucket table, the error word)
+// at the start of each call, and two calls that overlap on one GPU race.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+
+#include "sgs.h"
+#include "sgs_device.h"
+
+using namespace sgs;
+
+namespace {
+
+constexpr size_t kMaxN = SGS_NOALLOC_MAX_POINTS;   // points per call
+constexpr size_t kMaxB = 2 * kMaxN;                // buckets: pow2ceil(2 n) <= 2 * kMaxN (kMaxN is a power of two)
+static_assert((kMaxN & (kMaxN - 1)) == 0, "SGS_NOALLOC_MAX_POINTS must be a power of two");
+
+constexpr size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// layout of the array (byte offsets, each 256-B aligned)
+constexpr size_t kOffInX = 0;
+constexpr size_t kOffInY = kOffInX + align256(kMaxN * sizeof(double));
+constexpr size_t kOffInZ = kOffInY + align256(kMaxN * sizeof(double));
+constexpr size_t kOffInL = kOffInZ + align256(kMaxN * sizeof(double));
+constexpr size_t kOffOutX = kOffInL + align256(kMaxN * sizeof(int32_t));
+constexpr size_t kOffOutY = kOffOutX + align256(kMaxN * sizeof(double));
+constexpr size_t kOffOutZ = kOffOutY + align256(kMaxN * sizeof(double));
+constexpr size_t kOffOutL = kOffOutZ + align256(kMaxN * sizeof(double));
+constexpr size_t kOffOutI = kOffOutL + align256(kMaxN * sizeof(int32_t));
+constexpr size_t kOffTable = kOffOutI + align256(kMaxN * sizeof(int32_t));
+constexpr size_t kOffHome = kOffTable + align256(kMaxB * sizeof(DsEntry));
+constexpr size_t kOffBlockSum = kOffHome + align256(kMaxB * sizeof(int32_t));
+constexpr size_t kOffSim = kOffBlockSum + align256((kMaxB / 1024 + 2) * sizeof(int32_t));
+constexpr size_t kOffLay = kOffSim + align256(kMaxB * 2 * sizeof(int32_t));
+constexpr size_t kOffOrder = kOffLay + align256(kMaxB * 2 * sizeof(int32_t));
+constexpr size_t kOffState = kOffOrder + align256(kMaxN * sizeof(int32_t));
+constexpr size_t kOffSizes = kOffState + align256(sizeof(DevState));
+constexpr size_t kScratchBytes = kOffSizes + 256;  // int32[2]: n_in, n_out
+
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];  // ~17.6 MB per GPU the library runs on
+
+constexpr int kMaxDevices = 64;
+std::mutex g_mu;
+unsigned char *g_ptr[kMaxDevices] = {nullptr};  // per device: address of ITS copy of `scratch`
+thread_local char g_err[256] = "";
+
+int nfail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+constexpr int kBlock = 256;
+
+// AoS (n x 3 doubles, labels) -> the SoA layout the downsample kernels read; thread 0 also resets the per-call words
+__global__ __launch_bounds__(kBlock) void noalloc_stage_in_kernel(const double *__restrict__ xyz, const int32_t *__restrict__ label,
+                                                                  int n, CloudView in, DevState *st, int32_t *sizes) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) {
+        st->err_flags = 0;
+        sizes[0] = n;
+        sizes[1] = 0;
+    }
+    if (i >= n) return;
+    in.x[i] = xyz[3 * (size_t)i];
+    in.y[i] = xyz[3 * (size_t)i + 1];
+    in.z[i] = xyz[3 * (size_t)i + 2];
+    in.l[i] = label[i];
+}
+
+// SoA result -> the caller's AoS outputs (what fits in out_cap), count + status words
+__global__ __launch_bounds__(kBlock) void noalloc_stage_out_kernel(CloudView out, const int32_t *__restrict__ out_index,
+                                                                   const int32_t *__restrict__ sizes, const DevState *st, int out_cap,
+                                                                   double *__restrict__ out_xyz, int32_t *__restrict__ out_label,
+                                                                   int32_t *__restrict__ out_index_user, int32_t *__restrict__ out_n2) {
+    const int m = sizes[1];
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k == 0) {
+        out_n2[0] = m;
+        out_n2[1] = st->err_flags;
+    }
+    if (k >= m || k >= out_cap) return;
+    if (out_xyz) {
+        out_xyz[3 * (size_t)k] = out.x[k];
+        out_xyz[3 * (size_t)k + 1] = out.y[k];
+        out_xyz[3 * (size_t)k + 2] = out.z[k];
+    }
+    if (out_label) out_label[k] = out.l[k];
+    if (out_index_user) out_index_user[k] = out_index[k];
+}
+
+}  // namespace
+
+namespace sgs {
+// Resolves the address of the current device's copy of `scratch` (once per device).  Returns SGS_OK or SGS_EHIP.
+int noalloc_setup_device(int device) {
+    if (device < 0 || device >= kMaxDevices) return SGS_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ptr[device]) return SGS_OK;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return SGS_EHIP;
+    if (cur != device && hipSetDevice(device) != hipSuccess) return SGS_EHIP;
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (cur != device) hipSetDevice(cur);
+    if (e != hipSuccess || !p) return SGS_EHIP;
+    g_ptr[device] = (unsigned char *)p;
+    return SGS_OK;
+}
+const char *noalloc_last_error() { return g_err; }
+}  // namespace sgs
+
+extern "C" int sgs_voxel_downsample_dev_noalloc(const double *xyz_dev, const int32_t *label_dev, int n, double voxel_size,
+                                                double *out_xyz_dev, int32_t *out_label_dev, int32_t *out_index_dev, int out_cap,
+                                                int32_t *out_n2_dev, void *hip_stream) {
+    g_err[0] = 0;
+    if (n < 0 || out_cap < 0 || !(voxel_size > 0) || !out_n2_dev || (n && (!xyz_dev || !label_dev)))
+        return nfail(SGS_EINVAL, "sgs_voxel_downsample_dev_noalloc: bad argument");
+    if ((size_t)n > kMaxN)
+        return nfail(SGS_ECAPACITY, "sgs_voxel_downsample_dev_noalloc: n=%d exceeds SGS_NOALLOC_MAX_POINTS=%d (the fixed scratch array)", n,
+                     (int)kMaxN);
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess) return nfail(SGS_EHIP, "sgs_voxel_downsample_dev_noalloc: no current HIP device");
+    if (device < 0 || device >= kMaxDevices) return nfail(SGS_EINVAL, "sgs_voxel_downsample_dev_noalloc: device %d not supported", device);
+    unsigned char *base = g_ptr[device];
+    if (!base) {  // first call on this device and no context was ever created on it
+        const int r = noalloc_setup_device(device);
+        if (r) return nfail(r, "sgs_voxel_downsample_dev_noalloc: hipGetSymbolAddress failed on device %d", device);
+        base = g_ptr[device];
+    }
+    hipStream_t s = (hipStream_t)hip_stream;
+    const CloudView in{(double *)(base + kOffInX), (double *)(base + kOffInY), (double *)(base + kOffInZ), (int32_t *)(base + kOffInL)};
+    const CloudView out{(double *)(base + kOffOutX), (double *)(base + kOffOutY), (double *)(base + kOffOutZ), (int32_t *)(base + kOffOutL)};
+    DevState *st = (DevState *)(base + kOffState);
+    int32_t *sizes = (int32_t *)(base + kOffSizes);
+    int32_t *index = (int32_t *)(base + kOffOutI);
+    const int nb = n > 0 ? (n + kBlock - 1) / kBlock : 1;
+    hipLaunchKernelGGL(noalloc_stage_in_kernel, dim3(nb), dim3(kBlock), 0, s, xyz_dev, label_dev, n, in, st, sizes);
+    if (n > 0) {
+        // the buckets this call uses must start empty whatever the last call on this GPU left behind
+        size_t B = 1;
+        while (B < 2 * (size_t)n) B <<= 1;
+        launch_downsample_table_clear(s, (DsEntry *)(base + kOffTable), B);
+        DsJob j;
+        j.in = in; j.n_in = sizes + 0; j.voxel = voxel_size;
+        j.table = (DsEntry *)(base + kOffTable);
+        j.homebase = (int32_t *)(base + kOffHome);
+        j.blocksum = (int32_t *)(base + kOffBlockSum);
+        j.sim = (int32_t *)(base + kOffSim);
+        j.lay = (int32_t *)(base + kOffLay);
+        j.order = (int32_t *)(base + kOffOrder);
+        j.out = out; j.out_index = index; j.n_out = sizes + 1;
+        launch_downsample(s, &j, 1, n, st);
+    }
+    hipLaunchKernelGGL(noalloc_stage_out_kernel, dim3(nb), dim3(kBlock), 0, s, out, index, sizes, st, out_cap, out_xyz_dev, out_label_dev,
+                       out_index_dev, out_n2_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nfail(SGS_EHIP, "sgs_voxel_downsample_dev_noalloc: launch failed: %s", hipGetErrorString(e));
+    return SGS_OK;
+}

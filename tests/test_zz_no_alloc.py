@@ -1,0 +1,126 @@
+"""sgs_voxel_downsample_dev_noalloc (include/sgs.h): the one entry point that allocates nothing.  Called through
+the C ABI with device buffers (allocated with the HIP runtime the library is linked against, over ctypes) and compared bit for bit - count, emission
+order, coordinates, labels - with sgs_voxel_downsample, the existing entry point it is a variant of, on two calls
+in a row, the second with a smaller input (the shared scratch array keeps the first call's contents)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from sg_slam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _Hip:
+    """The HIP runtime libsgs_hip.so itself is linked against (found among the process's mapped libraries), through
+    ctypes: device buffers for the test without a second runtime (torch ships its own copy) in the process."""
+    _rt = None
+
+    @classmethod
+    def rt(cls):
+        if cls._rt is None:
+            api.lib()
+            path = None
+            with open("/proc/self/maps") as fh:
+                for line in fh:
+                    if "libamdhip64" in line:
+                        path = line.split()[-1]
+                        break
+            assert path, "libsgs_hip.so did not bring a HIP runtime into the process"
+            rt = ctypes.CDLL(path)
+            rt.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+            rt.hipFree.argtypes = [ctypes.c_void_p]
+            rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            rt.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+            rt.hipSetDevice.argtypes = [ctypes.c_int]
+            cls._rt = rt
+        return cls._rt
+
+
+class _DevBuf:
+    def __init__(self, nbytes, fill=0xF9):
+        self.n = max(int(nbytes), 16)
+        self.p = ctypes.c_void_p()
+        assert _Hip.rt().hipMalloc(ctypes.byref(self.p), self.n) == 0
+        assert _Hip.rt().hipMemset(self.p, fill, self.n) == 0
+
+    @classmethod
+    def of(cls, arr):
+        b = cls(arr.nbytes)
+        if arr.nbytes:
+            assert _Hip.rt().hipMemcpy(b.p, arr.ctypes.data, arr.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        return b
+
+    def get(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            assert _Hip.rt().hipMemcpy(out.ctypes.data, self.p, out.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        _Hip.rt().hipFree(self.p)
+
+
+def _noalloc(xyz, lab, voxel, cap=None):
+    rt = _Hip.rt()
+    assert rt.hipSetDevice(0) == 0
+    n = len(xyz)
+    cap = n if cap is None else cap
+    d_xyz = _DevBuf.of(np.ascontiguousarray(xyz, dtype=np.float64))
+    d_lab = _DevBuf.of(np.ascontiguousarray(lab, dtype=np.int32))
+    o_xyz, o_lab, o_idx, o_n2 = _DevBuf(24 * (cap + 8)), _DevBuf(4 * (cap + 8)), _DevBuf(4 * (cap + 8)), _DevBuf(8)
+    assert rt.hipDeviceSynchronize() == 0
+    r = api.lib().sgs_voxel_downsample_dev_noalloc(d_xyz.p if n else None, d_lab.p if n else None, n, float(voxel), o_xyz.p, o_lab.p,
+                                                   o_idx.p, cap, o_n2.p, None)
+    assert r == api.SGS_OK, api.lib().sgs_last_error(None)
+    assert rt.hipDeviceSynchronize() == 0
+    m, flags = (int(v) for v in o_n2.get(np.int32, 2))
+    k = min(m, cap)
+    gx = o_xyz.get(np.float64, 3 * (cap + 8)).reshape(-1, 3)
+    gl, gi = o_lab.get(np.int32, cap + 8), o_idx.get(np.int32, cap + 8)
+    for b in (d_xyz, d_lab, o_xyz, o_lab, o_idx, o_n2):
+        b.free()
+    return m, flags, gx[:k], gl[:k], gi[:k], gi[k:]
+
+
+def test_noalloc_downsample_matches_the_allocating_entry_point_twice_in_a_row(ctx_small):
+    _, _, lab_big = synth.scan(11, "hdl64")
+    xyz_big = synth.scan(11, "hdl64")[0][:, :3].astype(np.float64)
+    xyz_small = synth.scan(12, "small")[0][:, :3].astype(np.float64)
+    lab_small = synth.scan(12, "small")[2]
+    assert len(xyz_small) < len(xyz_big) <= api.NOALLOC_MAX_POINTS
+    # first call: a full 120 000-point scan; second call: a smaller input on the same (now dirty) scratch; then big again
+    for xyz, lab, voxel in ((xyz_big, lab_big, 0.5), (xyz_small, lab_small, 0.2), (xyz_small[:1], lab_small[:1], 1.5),
+                            (xyz_big, lab_big, 0.2)):
+        m, flags, gx, gl, gi, _ = _noalloc(xyz, lab, voxel)
+        ex, el, ei = ctx_small.VoxelDownsampleSemantic(xyz, lab, voxel)
+        assert flags == 0 and m == len(ei)
+        assert np.array_equal(gi, ei), "emission order differs"
+        assert np.array_equal(gx, ex) and np.array_equal(gl, el)
+
+
+def test_noalloc_downsample_edges_and_limits(ctx_small):
+    xyz = synth.scan(3, "small")[0][:, :3].astype(np.float64)
+    lab = synth.scan(3, "small")[2]
+    # output capacity smaller than the count: what fits is written, the full count is reported, the rest is untouched
+    ex, el, ei = ctx_small.VoxelDownsampleSemantic(xyz, lab, 0.5)
+    m, flags, gx, gl, gi, rest = _noalloc(xyz, lab, 0.5, cap=100)
+    assert m == len(ei) > 100 and np.array_equal(gi, ei[:100]) and np.array_equal(gx, ex[:100])
+    assert np.all(rest == np.int32(-101058055))  # 0xF9F9F9F9: nothing written past out_cap
+    # empty input
+    m, flags, gx, gl, gi, _ = _noalloc(np.zeros((0, 3)), np.zeros(0, dtype=np.int32), 0.5, cap=4)
+    assert m == 0 and flags == 0 and len(gi) == 0
+    # a key outside the packable range raises the flag, as the context entry point reports SGS_ECAPACITY
+    far = np.array([[3.0e6, 0.0, 0.0], [1.0, 2.0, 3.0]])
+    m, flags, *_ = _noalloc(far, np.zeros(2, dtype=np.int32), 1.0)
+    assert flags & 1
+    # beyond the fixed scratch array: rejected before anything is enqueued
+    L = api.lib()
+    r = L.sgs_voxel_downsample_dev_noalloc(1, 1, api.NOALLOC_MAX_POINTS + 1, 0.5, None, None, None, 0, 1, None)
+    assert r == api.SGS_ECAPACITY and b"SGS_NOALLOC_MAX_POINTS" in L.sgs_last_error(None)
+    assert L.sgs_voxel_downsample_dev_noalloc(None, None, 5, 0.5, None, None, None, 0, 1, None) == api.SGS_EINVAL
+    assert L.sgs_voxel_downsample_dev_noalloc(1, 1, 5, 0.0, None, None, None, 0, 1, None) == api.SGS_EINVAL
+    # and the scratch is still good afterwards
+    m2, _, gx2, _, gi2, _ = _noalloc(xyz, lab, 0.5)
+    assert m2 == len(ei) and np.array_equal(gi2, ei)
