@@ -7,11 +7,11 @@
 // once, one per half of the wavefront - see wave_nearest<.., HALF> and accumulate_queries).  Lanes 0..26 probe the 27 neighbour
 // voxels in the reference's x-outer / z-inner order (one 16-B slot-header load per probe gives key +
 // count).  The occupied voxels are compacted across the wave with ds_permute (cross-lane through the
-// LDS crossbar, no LDS allocation), and their points - voxel-local fp32 (x,y,z,label) records stored
-// contiguously per voxel - are read 64 candidates at a time as coalesced 16-B loads straight into
+// LDS crossbar, no LDS allocation), and their points - 32-byte (fp64 x,y,z world coordinates, label) records
+// stored contiguously per voxel - are read 64 candidates at a time as coalesced loads straight into
 // registers (each candidate is used once; staging it in LDS would only add a round trip).
-// Nearest neighbour = min over (fp32 squared distance, visiting ordinal) packed in one u64, reduced by
-// wave shuffles; first-wins tie-break like the reference's strict '<'.
+// Nearest neighbour = min over (the reference's fp64 squared distance, visiting ordinal), reduced by
+// wave shuffles; first-wins tie-break like the reference's strict '<': the SAME neighbour as the CPU path, always.
 // The robust weighted normal equations need only 16 moment sums (J = [I | -hat(s)] is fixed by s):
 //   W = sum w, S = sum w s, P = sum w s s^T (6), bt = sum w ws r, br = sum w ws (s x r)
 // accumulated in fp64 per wave, combined per block through LDS in fixed order, written as per-block
@@ -21,6 +21,10 @@
 #include <type_traits>
 
 #include "sgs_device.h"
+
+#ifndef SGS_ICP_ROUNDS
+#define SGS_ICP_ROUNDS 2  // candidate rounds per chunk of the neighbour search (32-byte records: 8 registers each)
+#endif
 
 namespace sgs {
 
@@ -47,8 +51,10 @@ __device__ inline int32_t voxel_coord_fast(double x, double voxel, double inv) {
 // per-kernel constants of the neighbour search
 struct SearchConst {
     double inv_voxel;
-    uint32_t cap_magic;  // ceil(2^32 / cap): c / cap == (c * cap_magic) >> 32 for c < 27 * 255
+    uint32_t cap_magic;  // ceil(2^32 / cap): c / cap == (c * cap_magic) >> 32 for c < 27 * 255; 0 stands for cap == 1 (2^32 does not fit)
 };
+// c / cap for a flat candidate index c < 27 * 255
+__device__ inline int div_cap(uint32_t c, const SearchConst &sc) { return sc.cap_magic ? (int)__umulhi(c, sc.cap_magic) : (int)c; }
 __device__ inline SearchConst search_const(const MapView &m) {
     return SearchConst{1.0 / m.voxel, 0xFFFFFFFFu / (uint32_t)m.cap + 1u};
 }
@@ -91,13 +97,12 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     int slot = -1;
     uint32_t cnt = 0;
     int probes = 0;
-    float relx = 0.f, rely = 0.f, relz = 0.f;
     if (lane < 27 && answer) {
         const K3 kn{kc.x + lane / 9 - 1, kc.y + (lane / 3) % 3 - 1, kc.z + lane % 3 - 1};
-        // the query in this voxel's frame (voxel origin = key * voxel_size), rounded to fp32 once
-        relx = (float)(w.x - (double)kn.x * m.voxel);
-        rely = (float)(w.y - (double)kn.y * m.voxel);
-        relz = (float)(w.z - (double)kn.z * m.voxel);
+        // the query in this voxel's frame (voxel origin = key * voxel_size), fp32 is plenty for the skip test
+        const float relx = (float)(w.x - (double)kn.x * m.voxel);
+        const float rely = (float)(w.y - (double)kn.y * m.voxel);
+        const float relz = (float)(w.z - (double)kn.z * m.voxel);
         const float vs = (float)m.voxel;
         auto axis_gap = [vs](float rel, int k) {  // distance from the query to the voxel's extent along one axis
             const float lo = k > 0 ? 0.f : -vs, hi = k < 0 ? 0.f : vs;
@@ -130,34 +135,33 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     const int dst = (hb + (occ ? before : nf + (lane - before))) << 2;
     const int c_slot = __builtin_amdgcn_ds_permute(dst, slot);
     const int c_meta = __builtin_amdgcn_ds_permute(dst, (int)(cnt | ((uint32_t)lane << 8)));
-    const float c_relx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(relx)));
-    const float c_rely = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(rely)));
-    const float c_relz = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(relz)));
-    // candidates: compacted voxel k, point p  <->  flat index c = k*cap + p, 64 per round.  Rounds are
-    // fetched in chunks of three, and the NEXT chunk's loads are issued before the current chunk's
-    // distances are computed, so a query with many occupied voxels still costs about one memory
-    // round trip.
-    unsigned long long best = ~0ull;
-    float bx = 0.f, by = 0.f, bz = 0.f;
+    // candidates: compacted voxel k, point p  <->  flat index c = k*cap + p, W per round.  Rounds are fetched in
+    // chunks, and the NEXT chunk's loads are issued before the current chunk's distances are computed, so a query
+    // with many occupied voxels still costs about one memory round trip.
+    // Distances are the reference's own: (neighbor - point).squaredNorm() in fp64 on world coordinates
+    // (F/VoxelHashMap.cpp:86), strict '<' in visiting order (:87) - the same bits, hence the same neighbour, as the
+    // CPU path, exact ties included (first visited wins: a lane meets its candidates in visiting order, and across
+    // lanes the smaller visiting ordinal breaks a tie).
+    double bestd = __longlong_as_double(0x7FF0000000000000ll);  // +inf: nothing found yet
+    int bestord = INT_MAX;
+    double bx = 0.0, by = 0.0, bz = 0.0;
     int blabel = 0;
     int ncand = 0;
     const int total = nf * m.cap;
-    constexpr int kRounds = 3;
+    constexpr int kRounds = SGS_ICP_ROUNDS;
     struct Chunk {  // kept small: two of them are live across the loads, and the kernel is short of registers
-        float4 q[kRounds];
-        int kk[kRounds];   // byte address (bpermute) of the lane that holds the candidate's voxel
+        MapPoint q[kRounds];
         int ord[kRounds];  // visiting ordinal v*cap + p of the candidate, -1 = none
     };
     auto fetch = [&](int c0, Chunk &ch) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
             const int c = c0 + r * W + lane;
-            const int k = (int)__umulhi((uint32_t)c, sc.cap_magic);
+            const int k = div_cap((uint32_t)c, sc);
             const int p = c - k * m.cap;
             const int kk = (hb + (k < nf ? k : 0)) << 2;
             const int es = __builtin_amdgcn_ds_bpermute(kk, c_slot);
             const int em = __builtin_amdgcn_ds_bpermute(kk, c_meta);
-            ch.kk[r] = kk;
             const bool valid = k < nf && p < (em & 0xFF);
             ch.ord[r] = valid ? (em >> 8) * m.cap + p : -1;
             if (valid) ch.q[r] = m.pts[(size_t)es * m.cap + p];
@@ -166,18 +170,13 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     auto score = [&](const Chunk &ch) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
-            // the query in the candidate's voxel frame, from that voxel's lane (nothing here waits for the loads)
-            const float rx = __int_as_float(__builtin_amdgcn_ds_bpermute(ch.kk[r], __float_as_int(c_relx)));
-            const float ry = __int_as_float(__builtin_amdgcn_ds_bpermute(ch.kk[r], __float_as_int(c_rely)));
-            const float rz = __int_as_float(__builtin_amdgcn_ds_bpermute(ch.kk[r], __float_as_int(c_relz)));
             if (ch.ord[r] < 0) continue;
-            const float dx = ch.q[r].x - rx, dy = ch.q[r].y - ry, dz = ch.q[r].z - rz;
-            const float d2 = dx * dx + (dy * dy + dz * dz);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)ch.ord[r];
-            if (key < best) {
-                best = key;
+            const double d2 = sq3(D3{ch.q[r].x - w.x, ch.q[r].y - w.y, ch.q[r].z - w.z});
+            if (d2 < bestd) {
+                bestd = d2;
+                bestord = ch.ord[r];
                 bx = ch.q[r].x; by = ch.q[r].y; bz = ch.q[r].z;
-                blabel = __float_as_int(ch.q[r].w);
+                blabel = ch.q[r].label;
             }
             ++ncand;
         }
@@ -192,11 +191,15 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
         }
         score(cur);
     }
-    unsigned long long wbest = best;
+    double wd = bestd;
+    int wo = bestord;
 #pragma unroll
     for (int o = W / 2; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(wbest, o);
-        wbest = other < wbest ? other : wbest;
+        const double od = __shfl_xor(wd, o);
+        const int oo = __shfl_xor(wo, o);
+        const bool take = od < wd || (od == wd && oo < wo);
+        wd = take ? od : wd;
+        wo = take ? oo : wo;
     }
 #pragma unroll
     for (int o = W / 2; o > 0; o >>= 1) {
@@ -206,17 +209,14 @@ __device__ inline QueryResult wave_nearest(const MapView &m, const SearchConst &
     QueryResult r;
     r.candidates = ncand;
     r.probes = probes;
-    r.found = wbest != ~0ull;
+    r.found = wo != INT_MAX;
     r.label = 0;
     r.target = D3{0, 0, 0};
-    const unsigned long long winners = __ballot(best == wbest);
+    const unsigned long long winners = __ballot(bestord == wo);  // ordinals are unique within a query
     if (r.found) {
         const int winner = hb + __ffsll((long long)(HALF ? ((winners >> hb) & 0xFFFFFFFFull) : winners)) - 1;
-        const float fx = __shfl(bx, winner), fy = __shfl(by, winner), fz = __shfl(bz, winner);
+        r.target = D3{__shfl(bx, winner), __shfl(by, winner), __shfl(bz, winner)};
         r.label = __shfl(blabel, winner);
-        const int v = (int)__umulhi((uint32_t)(wbest & 0xFFFFFFFFull), sc.cap_magic);
-        r.target = D3{(double)(kc.x + v / 9 - 1) * m.voxel + (double)fx, (double)(kc.y + (v / 3) % 3 - 1) * m.voxel + (double)fy,
-                      (double)(kc.z + v % 3 - 1) * m.voxel + (double)fz};
     }
     return r;
 }
@@ -632,10 +632,15 @@ __global__ __launch_bounds__(kIcpThreads, SGS_ICP_MIN_WAVES) void icp_persistent
     // no dispatch in between - written into the host mirror by the host
     const bool host_init = mirror && mirror->init_enabled != 0;
     if (host_init && mirror->init_enabled == 2) {  // test hook (SGS_TEST_ABORT_EVERY): behave as if the inter-block wait ran out
-        if (threadIdx.x == 0 && blockIdx.x == 0) st->icp_abort = 1;
-        if (threadIdx.x == 0) __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0 && blockIdx.x == 0) {  // ONE place publishes the decision: block 0
+            st->icp_abort = 1;
+            __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
+    // a launch without icp_init_kernel in front clears the abort word itself: a launch that gave up and was then
+    // dropped by the host (cancel_chained_icp) must not make the NEXT scan's queued map update skip itself
+    if (host_init && blockIdx.x == 0 && threadIdx.x == 0) st->icp_abort = 0;
     Rigid T_total;
     double max_corr, th;
     int max_iter;
@@ -719,8 +724,10 @@ __global__ __launch_bounds__(kIcpThreads, SGS_ICP_MIN_WAVES) void icp_persistent
         }
         __syncthreads();
         if (s_flag) {
-            if (threadIdx.x == 0 && blockIdx.x == 0) st->icp_abort = 1;  // a map update queued behind this launch skips itself
-            if (threadIdx.x == 0 && mirror) __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // any block that gives up makes a map update queued behind this launch skip itself; the host is told by
+            // block 0 alone (it sees the abort mark in the counters at its next wait, or in its last look below)
+            if (threadIdx.x == 0) st->icp_abort = 1;
+            if (threadIdx.x == 0 && blockIdx.x == 0 && mirror) __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
         SGS_STAMP(ts2);
@@ -766,7 +773,19 @@ __global__ __launch_bounds__(kIcpThreads, SGS_ICP_MIN_WAVES) void icp_persistent
         if (done) break;
         __syncthreads();  // S, s_T, s_flag and red are rewritten by the next iteration
     }
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (blockIdx.x != 0 || wave != 0) return;
+    {   // a block whose wait ran out during the LAST iteration while this one passed: the loop did not end cleanly
+        // for every block, so it counts as given up (the host repeats it) - the decision is block 0's alone
+        const uint32_t t = lane < kIcpTickets ? __hip_atomic_load(&tickets[lane * kIcpTicketStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (__any(t >= kAbortBit)) {
+            if (lane == 0) {
+                st->icp_abort = 1;
+                if (mirror) __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
+    if (lane != 0) return;
     const long long corr = s_cnt[0], cand = s_cnt[1], probe = s_cnt[2];
     if (mirror && mirror->init_enabled != 0) {  // what icp_init_kernel would have left
         const int32_t *z = mirror->init_sizes4;

@@ -1,7 +1,7 @@
 // GPU-resident voxel hash map (F/VoxelHashMap.{hpp,cpp}): open addressing with linear probing over
 // 16-byte slot headers {packed key, count, pending-list head}; slot s owns the storage block
-// pts[s*cap .. s*cap+cap) of voxel-local fp32 offsets + label, so a find is one 16-B load and a
-// voxel's points are one contiguous coalesced read.
+// pts[s*cap .. s*cap+cap) of 32-byte point records (fp64 world coordinates + label), so a find is one 16-B load
+// and a voxel's points are one contiguous coalesced read.
 //
 // AddPoints semantics to preserve (F/VoxelHashMap.cpp:164-176): points are inserted sequentially in
 // input order and a voxel keeps at most `cap` points first-come.  Parallel version:
@@ -102,13 +102,7 @@ __global__ __launch_bounds__(kBlock) void map_append_kernel(MapView m, CloudView
     for (int j = head; j >= 0; j = next[j]) rank += (j < i) ? 1 : 0;
     const int pos = cnt0 + rank;
     if (pos >= m.cap) return;
-    const K3 k = unpack_key(raw.x);
-    const double ox = (double)k.x * m.voxel, oy = (double)k.y * m.voxel, oz = (double)k.z * m.voxel;
-    const double wx = world.x[i], wy = world.y[i], wz = world.z[i];
-    m.pts[(size_t)s * m.cap + pos] = make_float4((float)(wx - ox), (float)(wy - oy), (float)(wz - oz), __int_as_float(in.l[i]));
-    if (pos == 0) {
-        m.first[3 * (size_t)s] = wx; m.first[3 * (size_t)s + 1] = wy; m.first[3 * (size_t)s + 2] = wz;
-    }
+    m.pts[(size_t)s * m.cap + pos] = MapPoint{world.x[i], world.y[i], world.z[i], in.l[i], 0};
     (void)st;
 }
 
@@ -133,8 +127,8 @@ __global__ __launch_bounds__(kBlock) void map_prune_kernel(MapView m, const Rigi
         bool kill = false;
         if (valid && do_prune) {
             const D3 o = T_dev ? T_dev->t : origin_host;
-            const D3 f{m.first[3 * (size_t)s], m.first[3 * (size_t)s + 1], m.first[3 * (size_t)s + 2]};
-            kill = sq3(sub(f, o)) > max_d2;
+            const MapPoint f = m.pts[(size_t)s * m.cap];  // points.front() (F/VoxelHashMap.cpp:181)
+            kill = sq3(sub(D3{f.x, f.y, f.z}, o)) > max_d2;
         }
         live = (valid && !kill) ? 1 : 0;
         tomb = (key == kTombKey || kill) ? 1 : 0;
@@ -213,9 +207,6 @@ __global__ __launch_bounds__(kBlock) void map_rehash_kernel(MapView from, MapVie
     }
     to.slots[d].cnt = e.cnt;
     for (uint32_t j = 0; j < e.cnt; ++j) to.pts[(size_t)d * to.cap + j] = from.pts[(size_t)s * from.cap + j];
-    to.first[3 * (size_t)d] = from.first[3 * (size_t)s];
-    to.first[3 * (size_t)d + 1] = from.first[3 * (size_t)s + 1];
-    to.first[3 * (size_t)d + 2] = from.first[3 * (size_t)s + 2];
     (void)st;
 }
 

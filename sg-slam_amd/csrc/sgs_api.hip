@@ -33,7 +33,7 @@ struct CloudBuf {
 };
 
 struct MapBuf {
-    MapView v{nullptr, nullptr, nullptr, 0, 0, 0.0, 0, 1, 3};
+    MapView v{nullptr, nullptr, 0, 0, 0.0, 0, 1, 3};
     int log2cap = 0;
 };
 
@@ -266,17 +266,14 @@ int alloc_cloud(sgs_ctx *c, CloudView *v, size_t n) {
 
 int alloc_map(sgs_ctx *c, MapBuf *m, int log2cap) {
     const size_t cap = (size_t)1 << log2cap;
-    void *a = nullptr, *b = nullptr, *d = nullptr;
-    if (hipMalloc(&a, cap * sizeof(MapSlot)) != hipSuccess || hipMalloc(&b, cap * (size_t)c->cfg.max_points_per_voxel * sizeof(float4)) != hipSuccess ||
-        hipMalloc(&d, cap * 3 * sizeof(double)) != hipSuccess) {
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, cap * sizeof(MapSlot)) != hipSuccess || hipMalloc(&b, cap * (size_t)c->cfg.max_points_per_voxel * sizeof(MapPoint)) != hipSuccess) {
         if (a) hipFree(a);
         if (b) hipFree(b);
-        if (d) hipFree(d);
         return fail(c, SGS_ENOMEM, "voxel map allocation failed (2^%d slots)", log2cap);
     }
     m->v.slots = (MapSlot *)a;
-    m->v.pts = (float4 *)b;
-    m->v.first = (double *)d;
+    m->v.pts = (MapPoint *)b;
     m->v.mask = (uint32_t)(cap - 1);
     m->v.cap = c->cfg.max_points_per_voxel;
     m->v.voxel = c->cfg.voxel_size;
@@ -287,8 +284,7 @@ int alloc_map(sgs_ctx *c, MapBuf *m, int log2cap) {
 void free_map(MapBuf *m) {
     if (m->v.slots) hipFree(m->v.slots);
     if (m->v.pts) hipFree(m->v.pts);
-    if (m->v.first) hipFree(m->v.first);
-    m->v.slots = nullptr; m->v.pts = nullptr; m->v.first = nullptr;
+    m->v.slots = nullptr; m->v.pts = nullptr;
 }
 
 int sync_state(sgs_ctx *c) {
@@ -1373,29 +1369,24 @@ int sgs_map_size(sgs_ctx *c, int *voxels, int *points) {
     if (points) *points = c->map_points_host;
     return SGS_OK;
 }
-static int map_download(sgs_ctx *c, std::vector<MapSlot> &slots, std::vector<float4> &pts) {
+static int map_download(sgs_ctx *c, std::vector<MapSlot> &slots, std::vector<MapPoint> &pts) {
     const size_t cap = (size_t)c->map.v.mask + 1;
     slots.resize(cap);
     pts.resize(cap * (size_t)c->map.v.cap);
     SGS_HIP(c, hipMemcpyAsync(slots.data(), c->map.v.slots, cap * sizeof(MapSlot), hipMemcpyDeviceToHost, c->stream));
-    SGS_HIP(c, hipMemcpyAsync(pts.data(), c->map.v.pts, pts.size() * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    SGS_HIP(c, hipMemcpyAsync(pts.data(), c->map.v.pts, pts.size() * sizeof(MapPoint), hipMemcpyDeviceToHost, c->stream));
     SGS_HIP(c, hipStreamSynchronize(c->stream));
     return SGS_OK;
 }
-static inline void slot_point(const sgs_ctx *c, const MapSlot &e, const float4 &q, double *o) {
-    const K3 k = unpack_key(e.key);
-    o[0] = (double)k.x * c->map.v.voxel + (double)q.x;
-    o[1] = (double)k.y * c->map.v.voxel + (double)q.y;
-    o[2] = (double)k.z * c->map.v.voxel + (double)q.z;
-    int lab;
-    memcpy(&lab, &q.w, sizeof(int));
-    o[3] = (double)lab;
+static inline void slot_point(const sgs_ctx *, const MapSlot &, const MapPoint &q, double *o) {
+    o[0] = q.x; o[1] = q.y; o[2] = q.z;
+    o[3] = (double)q.label;
 }
 int sgs_map_pointcloud(sgs_ctx *c, double *xyzl, int cap, int *n) {
     ENTER(c);
     if (!n) return SGS_EINVAL;
     std::vector<MapSlot> slots;
-    std::vector<float4> pts;
+    std::vector<MapPoint> pts;
     int r;
     if ((r = map_download(c, slots, pts))) return r;
     int m = 0;
@@ -1413,7 +1404,7 @@ int sgs_map_dump(sgs_ctx *c, int max_voxels, int32_t *keys, int32_t *counts, dou
     ENTER(c);
     if (!n_voxels) return SGS_EINVAL;
     std::vector<MapSlot> slots;
-    std::vector<float4> pts;
+    std::vector<MapPoint> pts;
     int r;
     if ((r = map_download(c, slots, pts))) return r;
     std::vector<size_t> live;

@@ -41,16 +41,22 @@ struct DsJob {
 
 // ---- GPU-resident voxel hash map (F/VoxelHashMap.hpp:37-83) ----
 // open addressing, linear probing, slot == storage block.  16-byte slot header so one load gives
-// key + count; points are voxel-local fp32 offsets (x,y,z) + label bits, cap per voxel contiguous.
+// key + count; points are 32-byte records - the world coordinates as the very doubles the reference stores
+// (F/VoxelHashMap.cpp:153-175) + the label - cap per voxel contiguous, so that the nearest-neighbour search
+// computes the reference's fp64 squared distances bit for bit and picks the same point, ties included.
 struct MapSlot {
     unsigned long long key;  // packed key, kEmptyKey or kTombKey
     uint32_t cnt;            // points stored (<= cap)
     int32_t head;            // per-batch pending list head (-1 outside sgs_map_add), see k_map.hip
 };
+struct __attribute__((aligned(32))) MapPoint {
+    double x, y, z;   // world frame
+    int32_t label;
+    int32_t pad;
+};
 struct MapView {
     MapSlot *slots;
-    float4 *pts;      // [slot][cap]
-    double *first;    // [slot][3]: world coordinates of the voxel's oldest point (prune predicate)
+    MapPoint *pts;    // [slot][cap]; [slot][0] is the voxel's oldest point (prune predicate)
     uint32_t mask;    // capacity - 1
     int32_t cap;      // max points per voxel
     double voxel;

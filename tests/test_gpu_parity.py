@@ -128,13 +128,15 @@ def test_downsample_properties_at_full_size(ctx_small):
 
 
 # ---------------- VoxelHashMap ----------------
-def _compare_maps(ctx, om, atol=1e-6):
+def _compare_maps(ctx, om, atol=0.0):
+    """atol = 0: the stored world coordinates are the oracle's doubles bit for bit (same transform arithmetic on the
+    same pose); a pipeline run passes the rounding-level pose difference of the scans that stored the points."""
     ko, co, po = om.dump()
     kg, cg, pg = ctx.map_dump()
     assert np.array_equal(ko, kg), "voxel key sets differ"
     assert np.array_equal(co, cg), "per-voxel counts differ"
     assert np.array_equal(po[..., 3], pg[..., 3]), "labels / in-voxel order differ"
-    assert np.abs(po - pg).max() < atol  # points are stored as voxel-local fp32 offsets
+    assert np.abs(po - pg).max() <= atol, np.abs(po - pg).max()
     assert ctx.map_size() == om.size()
 
 
@@ -167,7 +169,7 @@ def test_map_cap_and_order_within_voxel():
     ctx.AddPoints(pts[7:])
     keys, cnt, p = ctx.map_dump()
     assert keys.tolist() == [[0, 0, 0]] and cnt.tolist() == [20]
-    assert np.array_equal(p[0, :, 3], pts[:20, 3]) and np.abs(p[0] - pts[:20]).max() < 1e-6
+    assert np.array_equal(p[0, :, 3], pts[:20, 3]) and np.array_equal(p[0], pts[:20])
     # a large unordered batch into few voxels: still first-come in input order
     big = np.concatenate([RNG.random((5000, 3)) * [2, 1, 1], np.arange(5000)[:, None] % 20], axis=1)
     ctx.Clear()
@@ -224,19 +226,40 @@ def _source(frame, shape="small"):
     return sx, sl
 
 
+def _check_correspondences(ctx, om, q, md):
+    """GetCorrespondences of the library against the oracle's, query by query, unconditionally.  Both score the
+    candidates as the reference does - fp64 squared distance on world coordinates, first visited wins - so every
+    query must get the same map point, bit for bit, and the same verdict at the distance gate.  (The comparison
+    still classifies a mismatch - another neighbour at an equal distance, a neighbour on the gate - so a failure
+    says what happened.)  Returns the number of queries resolved differently: must be 0."""
+    so, to, qo, _ = om.get_correspondences(q, md)
+    sg, tg, qg = ctx.GetCorrespondences(q, md)
+    o = {int(i): (s, t) for i, s, t in zip(qo, so, to)}
+    g = {int(i): (s, t) for i, s, t in zip(qg, sg, tg)}
+    assert list(qg) == sorted(qg) and list(qo) == sorted(qo)  # query order preserved (ordered concat join, F/VoxelHashMap.cpp:120-128)
+    flips = 0
+    for i in sorted(set(o) | set(g)):
+        if i in o and i in g:
+            assert np.array_equal(o[i][0], g[i][0]) and np.array_equal(g[i][0], q[i])  # the source point, bit for bit
+            if np.array_equal(o[i][1], g[i][1]):
+                continue  # the same map point: coordinates and label bit for bit
+            do, dg = np.linalg.norm(q[i, :3] - o[i][1][:3]), np.linalg.norm(q[i, :3] - g[i][1][:3])
+            assert abs(do - dg) < 1e-6, f"query {i}: another neighbour, {dg} m against the oracle's {do} m"
+        else:  # one side dropped the query at the gate: its neighbour must sit on the gate
+            d = np.linalg.norm(q[i, :3] - (o[i] if i in o else g[i])[1][:3])
+            assert abs(d - md) < 1e-6, f"query {i}: kept by one side only, neighbour at {d} m, gate {md} m"
+        flips += 1
+    assert flips == 0, f"{flips} of {len(q)} queries resolved differently"  # fp64 world coordinates on both sides: the same bits
+    return flips
+
+
 def test_correspondences_match_oracle():
     ctx, om = _filled()
     sx, sl = _source(3)
     guess = O.se3_mul(synth.gt_pose(3), O.se3_exp([0.2, 0.05, 0, 0, 0, 0.01]))
     q = _xyzl(O.se3_act(guess, sx), sl)
     for md in (6.0, 1.0, 0.3):
-        so, to, qo, cand = om.get_correspondences(q, md)
-        sg, tg, qg = ctx.GetCorrespondences(q, md)
-        # the selected neighbour is identical unless two candidates tie within fp32 rounding
-        assert abs(len(qo) - len(qg)) <= 2
-        if np.array_equal(qo, qg):
-            assert np.array_equal(so, sg)
-            assert np.abs(to - tg).max() < 1e-6 and np.array_equal(to[:, 3], tg[:, 3])
+        _check_correspondences(ctx, om, q, md)
     # engineered ties: first visited voxel / first inserted point wins
     c2 = make_ctx()
     c2.AddPoints(np.array([[1.5, 0.5, 0.5, 7], [-0.5, 0.5, 0.5, 8]]))
@@ -265,7 +288,7 @@ def test_linear_system_matches_oracle():
     lg, ng = ctx.BuildLinearSystem(q, 6.0, 0.667)
     assert no == ng
     scale = np.abs(lo).max()
-    assert np.max(np.abs(lo - lg)) / scale < 1e-6  # fp32 voxel-local offsets, fp64 accumulation
+    assert np.max(np.abs(lo - lg)) / scale < 1e-10  # same correspondences and residuals, fp64 sums in another order (1e-10)
     # bit-reproducible run to run (fixed-order reduction, no atomics)
     lg2, _ = ctx.BuildLinearSystem(q, 6.0, 0.667)
     assert np.array_equal(lg, lg2)
@@ -286,10 +309,8 @@ def test_linear_system_with_two_queries_per_wavefront(nq):
     lo, no = om.build_linear_system(q, 6.0, 0.667)
     lg, ng = ctx.BuildLinearSystem(q, 6.0, 0.667)
     assert no == ng and no > nq // 2
-    assert np.max(np.abs(lo - lg)) / np.abs(lo).max() < 1e-6
-    so, to, qo, _ = om.get_correspondences(q, 1.0)
-    sg, tg, qg = ctx.GetCorrespondences(q, 1.0)
-    assert abs(len(qo) - len(qg)) <= 2
+    assert np.max(np.abs(lo - lg)) / np.abs(lo).max() < 1e-10
+    _check_correspondences(ctx, om, q, 1.0)
     ctx.close()
 
 
@@ -324,8 +345,8 @@ def test_register_frame_matches_oracle():
         po, info = om.register_frame(q, guess, 6.0, 0.667)
         et, er = pose_err(po, pg)
         assert et < POSE_TOL_M and er < POSE_TOL_RAD
-        assert et < 1e-6 and er < 1e-7
-        assert abs(itg - info["iterations"]) <= 1
+        assert et < 1e-9 and er < 1e-10
+        assert itg == info["iterations"]
     # empty map returns the guess untouched (F/Registration.cpp:152)
     c2 = make_ctx()
     g = O.se3_exp([1, 2, 3, 0.1, 0.2, 0.3])
@@ -382,7 +403,7 @@ def test_key_sharded_map_registers_like_one_map(world, block_log2):
         assert sorted(map(tuple, kg)) == sorted(map(tuple, want))
         for k, n, p in zip(kg, cg, pg):
             fn, fp = full[tuple(k)]
-            assert n == fn and np.array_equal(p[:n, 3], fp[:, 3]) and np.abs(p[:n] - fp).max() < 1e-6  # voxel-local fp32 offsets
+            assert n == fn and np.array_equal(p[:n, 3], fp[:, 3]) and np.array_equal(p[:n], fp)
     assert sum(int((shard_owner(ko, block_log2, world) == r).sum()) for r in range(world)) == len(ko)
     sx, sl = _source(3)
     q = _xyzl(sx, sl)
@@ -407,7 +428,7 @@ def test_key_sharded_map_registers_like_one_map(world, block_log2):
     pg, itg = out[0]
     et, er = pose_err(po_, pg)
     assert et < POSE_TOL_M and er < POSE_TOL_RAD
-    assert et < 1e-6 and er < 1e-7
+    assert et < 1e-9 and er < 1e-10
     assert abs(itg - info["iterations"]) <= 1 and ar.calls == itg + 1  # 28 doubles per iteration + the emptiness check
     for c in ctxs:
         c.close()
@@ -453,7 +474,7 @@ def test_key_sharded_registration_with_two_queries_per_wavefront():
     for pg, itg in out:
         assert np.array_equal(pg, out[0][0]) and itg == out[0][1]
     et, er = pose_err(po_, out[0][0])
-    assert et < 1e-6 and er < 1e-7
+    assert et < 1e-9 and er < 1e-10
     assert abs(out[0][1] - info["iterations"]) <= 1
     for c in ctxs:
         c.close()
@@ -489,7 +510,7 @@ def test_key_sharded_pipeline_matches_unsharded_pipeline():
         a, b = out[0][k], out[1][k]
         assert np.array_equal(a["pose"], b["pose"]) and a["iterations"] == b["iterations"]
         et, er = pose_err(want["pose"], a["pose"])
-        assert et < 1e-6 and er < 1e-7, (k, et, er)
+        assert et < 1e-9 and er < 1e-10, (k, et, er)
         assert abs(a["iterations"] - want["iterations"]) <= 1
         if a["iterations"] == want["iterations"]:  # summed over the iterations; a residual on the limit may flip
             assert abs(a["correspondences"] - want["correspondences"]) <= 2
@@ -513,7 +534,7 @@ def test_key_sharded_map_two_gloo_processes_one_gpu():
     a, b = res
     assert a["pose"] == b["pose"] and a["iters"] == b["iters"]
     et, er = pose_err(np.array(a["ref_pose"]), np.array(a["pose"]))
-    assert et < 1e-6 and er < 1e-7
+    assert et < 1e-9 and er < 1e-10
     assert abs(a["iters"] - a["ref_iters"]) <= 1
     assert max(a["voxels"], b["voxels"]) < a["full_voxels"] <= a["voxels"] + b["voxels"]
 
@@ -618,7 +639,7 @@ def _run_pipeline(shape, frames, kitti=False, use_f32=True, **cfgkw):
         ro = slam.process(xyz, lab, ts, kitti)
         for a in ("n_in", "n_cluster", "n_ds", "n_src", "map_voxels", "n_boxes"):
             assert rg[a] == ro[a], f"frame {k}: {a} {rg[a]} != {ro[a]}"
-        assert abs(rg["sigma"] - ro["sigma"]) < 1e-6  # sigma follows the poses, which agree to ~1e-9
+        assert abs(rg["sigma"] - ro["sigma"]) < 1e-9  # sigma follows the poses, which agree to ~1e-12
         et, er = pose_err(ro["pose"], rg["pose"])
         assert et < POSE_TOL_M and er < POSE_TOL_RAD, f"frame {k}: pose differs by {et} m / {er} rad"
         worst = (max(worst[0], et), max(worst[1], er))
@@ -635,7 +656,7 @@ def _run_pipeline(shape, frames, kitti=False, use_f32=True, **cfgkw):
                 assert ctx.boxes().shape == slam.boxes().shape and np.abs(ctx.boxes() - slam.boxes()).max() < 1e-6
             else:
                 assert np.array_equal(ctx.boxes(), slam.boxes())
-    _compare_maps(ctx, slam.map())
+    _compare_maps(ctx, slam.map(), atol=1e-9)
     assert np.allclose(ctx.poses()[-1], rg["pose"])
     ctx.close()
     return worst
@@ -643,7 +664,7 @@ def _run_pipeline(shape, frames, kitti=False, use_f32=True, **cfgkw):
 
 def test_pipeline_small_sequence():
     worst = _run_pipeline("small", 40)
-    assert worst[0] < 1e-6 and worst[1] < 1e-7
+    assert worst[0] < 1e-9 and worst[1] < 1e-10
 
 
 def test_pipeline_full_size_scans():
@@ -822,14 +843,14 @@ def test_fast_icp_matches_oracle(ctx_small, voxel, cap, ka, kb):
     pg, itg = ctx_small.FastIcpGetTrans(A, B, init, voxel, cap, 0.5)
     po, info = O.fast_icp(A, B, init, voxel, cap, 0.5)
     et, er = pose_err(po, pg)
-    assert et < 1e-6 and er < 1e-7, (et, er)
+    assert et < 1e-9 and er < 1e-10, (et, er)
     assert abs(itg - info["iterations"]) <= 1 and itg >= 2
     assert ctx_small.map_size() == before  # the odometry map is not touched
     # a wider gate changes the answer in both the same way (the gate is the caller's)
     pg2, _ = ctx_small.FastIcpGetTrans(A, B, init, voxel, cap, 2.0)
     po2, _ = O.fast_icp(A, B, init, voxel, cap, 2.0)
     et, er = pose_err(po2, pg2)
-    assert et < 1e-6 and er < 1e-7
+    assert et < 1e-9 and er < 1e-10
     # empty target cloud: the initial transform comes back (FastIcp.cpp:184)
     pg3, it3 = ctx_small.FastIcpGetTrans(A, np.zeros((0, 4)), init, voxel, cap, 0.5)
     assert it3 == 0 and np.allclose(pg3, init, atol=1e-15)
@@ -932,6 +953,70 @@ def test_pipeline_survives_a_one_launch_loop_that_gives_up(monkeypatch):
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
     for p in d_x + d_l:
         hip.hipFree(p)
+
+
+@pytest.mark.parametrize("every", [1, 2, 3])
+def test_dropped_launch_that_gave_up_does_not_poison_the_next_scan(monkeypatch, every):
+    """A chained launch that gives up (SGS_TEST_ABORT_EVERY) and is then DROPPED because the caller processes another
+    scan than the one it hinted at: its abort word must not make the next scan's queued map update skip itself.
+    Poses, sizes and the final map are compared with the oracle's."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    scans = [synth.scan(k, "small") for k in range(16)]
+    n = len(scans[0][0])
+
+    def dev(a):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), a.nbytes) == 0 and hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+        return p
+    d_x = [dev(np.ascontiguousarray(s[0], dtype=np.float32)) for s in scans]
+    d_l = [dev(np.ascontiguousarray(s[2], dtype=np.int32)) for s in scans]
+    monkeypatch.setenv("SGS_TEST_ABORT_EVERY", str(every))
+    ctx = make_ctx(async_map_update=1)
+    slam = O.Slam(O.kitti_config())
+    res = api.SgsScanResult()
+    for k in range(len(scans)):
+        if k + 1 < len(scans):
+            hint = k + 1 if k % 3 != 1 else (k + 2) % len(scans)  # every third hint names a scan that does not come next
+            ctx.prefetch_scan_dev(d_x[hint].value, d_l[hint].value, n, "")
+        ctx.process_scan_dev(d_x[k].value, d_l[k].value, n, None, "", res)
+        ro = slam.process(scans[k][0][:, :3].astype(np.float64), scans[k][2])
+        assert (res.n_in, res.n_cluster, res.n_ds, res.n_src) == (ro["n_in"], ro["n_cluster"], ro["n_ds"], ro["n_src"]), k
+        et, er = pose_err(ro["pose"], np.array(res.pose[:]))
+        assert et < POSE_TOL_M and er < POSE_TOL_RAD, (k, et, er)
+    assert ctx.stats().icp_fallbacks >= 3
+    _compare_maps(ctx, slam.map(), atol=1e-9)
+    ctx.close()
+    for p in d_x + d_l:
+        hip.hipFree(p)
+
+
+def test_one_point_per_voxel_and_255_points_per_voxel():
+    """max_points_per_voxel at both ends of the accepted range: the flat candidate index -> (voxel, point) split of
+    the neighbour search must hold for cap = 1 (where the 2^32 / cap magic does not fit 32 bits) and cap = 255."""
+    for cap in (1, 2, 255):
+        ctx = make_ctx(max_points_per_voxel=cap)
+        om = O.Map(1.0, 100.0, cap)
+        for k in (0, 1, 2):
+            _, xyz, lab = _scan(k)
+            px, pl = O.preprocess(xyz, lab, 100.0, 5.0)
+            pts = _xyzl(px, pl) if cap == 255 else _xyzl(*O.voxel_downsample(px, pl, 0.5)[:2])  # cap 255: dense input fills voxels
+            om.update(pts, synth.gt_pose(k))
+            ctx.Update(pts, synth.gt_pose(k))
+        _compare_maps(ctx, om)
+        fullest = int(om.dump()[1].max())
+        assert fullest == cap if cap < 255 else 20 < fullest <= 255
+        sx, sl = _source(3)
+        guess = O.se3_mul(synth.gt_pose(3), O.se3_exp([0.2, 0.05, 0, 0, 0, 0.01]))
+        q = _xyzl(O.se3_act(guess, sx), sl)
+        _check_correspondences(ctx, om, q, 6.0)
+        pg, itg = ctx.RegisterFrameSemantic(_xyzl(sx, sl), guess, 6.0, 0.667)
+        po, info = om.register_frame(_xyzl(sx, sl), guess, 6.0, 0.667)
+        et, er = pose_err(po, pg)
+        assert et < 1e-9 and er < 1e-10 and itg == info["iterations"], (cap, et, er)
+        ctx.close()
 
 
 # ---------------- GraphMap: instance tracking + relocalization (SURVEY.md 8f row f1) ----------------
@@ -1094,3 +1179,153 @@ def test_pipeline_degenerate_scans_in_the_chained_stream():
     ctx.close()
     for a, b in d:
         hip.hipFree(a); hip.hipFree(b)
+
+
+# ---------------- configs the round-1 suite did not exercise ----------------
+def test_device_gauss_newton_loop_against_numpy_driven_loop():
+    """The device-side solve (wave_solve6: LDLT with Eigen's pivot rule), exp and pose composition, checked without
+    the oracle: a Gauss-Newton loop driven from Python - the library's own 27 scalars per iteration, then
+    numpy.linalg.solve on the 6x6 system and scipy's matrix exponential of the twist (Sophus tangent order [v; w],
+    F/Registration.cpp:111-112,165-172) - must end at the pose of the one-launch device loop, in as many iterations."""
+    from scipy.linalg import expm
+    from helpers import pose_matrix
+    ctx, om = _filled()
+    sx, sl = _source(3)
+    for dt in ([0.3, 0.05, 0.0, 0, 0, 0.01], [-0.4, 0.2, 0.05, 0.002, -0.003, 0.02]):
+        guess = O.se3_mul(synth.gt_pose(3), O.se3_exp(dt))
+        pg, itg = ctx.RegisterFrameSemantic(_xyzl(sx, sl), guess, 6.0, 0.667)
+        T = pose_matrix(guess)
+        its = 0
+        for its in range(1, 501):
+            w = sx @ T[:3, :3].T + T[:3, 3]
+            s27, _ = ctx.BuildLinearSystem(_xyzl(w, sl), 6.0, 0.667)
+            A = np.zeros((6, 6))
+            A[np.triu_indices(6)] = s27[:21]
+            A = A + A.T - np.diag(np.diag(A))
+            x = np.linalg.solve(A, -s27[21:])
+            X = np.zeros((4, 4))
+            X[:3, :3] = [[0, -x[5], x[4]], [x[5], 0, -x[3]], [-x[4], x[3], 0]]
+            X[:3, 3] = x[:3]
+            T = expm(X) @ T
+            if np.linalg.norm(x) < 1e-4:
+                break
+        Tg = pose_matrix(pg)
+        assert its == itg, (its, itg)
+        assert np.abs(Tg[:3, 3] - T[:3, 3]).max() < 1e-8 and np.abs(Tg[:3, :3] - T[:3, :3]).max() < 1e-9
+    ctx.close()
+
+
+def _long_run(shape, frames, cfg, ocfg, every=50, deskew=False, check_sizes=True):
+    """Pipeline against the oracle over a long drive; returns per-frame (translation, rotation) differences,
+    iteration-count differences and the per-scan results of both."""
+    ctx = api.Context(cfg)
+    slam = O.Slam(ocfg)
+    worst_t = worst_r = 0.0
+    max_it = 0
+    rows = []
+    for k in range(frames):
+        xyzi, xyz, lab = _scan(k, shape)
+        ts = synth.mulran_timestamps(len(xyz), *synth.SHAPES[shape][:2]) if deskew else None
+        rg = ctx.process_scan_f32(xyzi, lab, ts, "")
+        ro = slam.process(xyz, lab, ts, False)
+        if check_sizes:
+            for a in ("n_in", "n_cluster", "n_ds", "n_src"):
+                assert rg[a] == ro[a], f"frame {k}: {a} {rg[a]} != {ro[a]}"
+        et, er = pose_err(ro["pose"], rg["pose"])
+        assert et < POSE_TOL_M and er < POSE_TOL_RAD, f"frame {k}: pose differs by {et} m / {er} rad"
+        worst_t, worst_r = max(worst_t, et), max(worst_r, er)
+        max_it = max(max_it, abs(rg["iterations"] - ro["iterations"]))
+        rows.append((rg, ro))
+    return ctx, slam, worst_t, worst_r, max_it, rows
+
+
+def test_pipeline_1000_scan_sequence_stays_within_the_pose_bar(capsys):
+    """A 1 000-scan HDL-64-shaped drive (120 000 points per scan; KITTI 00 itself has 4 541 and is not available):
+    EVERY frame within 1e-4 m / 1e-5 rad of the oracle, cloud sizes equal on every frame, the map equal at the end;
+    the largest per-frame differences and iteration-count difference are printed for the record (pytest -s)."""
+    cfg = api.preset("kitti", max_points=1 << 17, map_capacity_log2=17)
+    ctx, slam, wt, wr, mi, rows = _long_run("hdl64", 1000, cfg, O.kitti_config())
+    for rg, ro in rows:
+        assert rg["map_voxels"] == ro["map_voxels"] and rg["n_boxes"] == ro["n_boxes"]
+    _compare_maps(ctx, slam.map(), atol=1e-9)  # map points inherit the (rounding-level) pose differences of the scans that stored them
+    ctx.close()
+    with capsys.disabled():
+        print(f"\n[1000-scan hdl64] max pose diff {wt:.3e} m / {wr:.3e} rad, max |iteration diff| {mi}")
+    assert wt < 1e-9 and wr < 1e-10 and mi == 0  # same correspondences, same residual bits: only summation order differs
+
+
+def test_pipeline_dense128_scans_match_oracle():
+    """BASELINE.json configs[4] shape on one GPU: 128 x 8192 = 1 048 576-point scans, dense_128 preset (2^21 map
+    slots), four scans through the whole pipeline against the oracle - clouds incl. order, boxes, map."""
+    cfg = api.preset("dense_128")
+    ctx, slam, wt, wr, mi, rows = _long_run("dense128", 4, cfg, O.kitti_config())
+    for rg, ro in rows:
+        assert rg["map_voxels"] == ro["map_voxels"] and rg["n_boxes"] == ro["n_boxes"]
+    assert rows[-1][0]["n_in"] > 600000 and rows[-1][0]["iterations"] > 0
+    for which in (0, 1, 2, 3):
+        gx, gl = ctx.cloud(which)
+        ox, ol = slam.cloud(which)
+        assert np.array_equal(gx, ox) and np.array_equal(gl, ol), f"cloud {which} differs"
+    assert np.array_equal(ctx.boxes(), slam.boxes())
+    _compare_maps(ctx, slam.map(), atol=1e-9)
+    assert wt < 1e-9 and wr < 1e-10 and mi == 0
+    ctx.close()
+
+
+def test_pipeline_mulran_shape_deskew_and_relocalization_together():
+    """BASELINE.json configs[2]: OS1-64-shaped scans (64 x 1024, +-16.6 deg), mulran preset (deskew on, graph-map range
+    60 m) with relocalization enabled, 60 scans with two 6-frame gaps that trip the model deviation.  Up to the first
+    relocalization the pipelines must agree to the pose bar; afterwards the graph-matched guesses may legitimately
+    differ (non-unique spectral descriptors), so the bar there is 5 cm - and the run must relocalize."""
+    cfg = api.preset("mulran", max_points=1 << 17, map_capacity_log2=17, relocalization_enable=1, inlier_rate_th=0.37)
+    ocfg = O.kitti_config(deskew=1, max_local_graph_map_range=60.0, relocalization_enable=1, inlier_rate_th=0.37)
+    ctx, slam = api.Context(cfg), O.Slam(ocfg)
+    frames = [k for k in range(60) if not (20 <= k < 26 or 40 <= k < 46)]
+    relocalized_once = False
+    for k in frames:
+        xyzi, xyz, lab = _scan(k, "os1_64")
+        ts = synth.mulran_timestamps(len(xyz), 64, 1024)
+        rg = ctx.process_scan_f32(xyzi, lab, ts, "")
+        ro = slam.process(xyz, lab, ts, False)
+        info, st = slam.graphmap_info(), ctx.stats()
+        et, er = pose_err(ro["pose"], rg["pose"])
+        if not relocalized_once:
+            assert (rg["n_in"], rg["n_cluster"], rg["n_ds"], rg["n_src"], rg["n_boxes"]) == (ro["n_in"], ro["n_cluster"], ro["n_ds"], ro["n_src"], ro["n_boxes"]), k
+            assert st.relocalization_attempts == info["attempts"] and rg["relocalized"] == info["relocalized"], k
+        relocalized_once = relocalized_once or rg["relocalized"] or info["relocalized"]
+        if relocalized_once:
+            assert et < 0.05 and er < 0.005, (k, et, er)
+        else:
+            assert et < POSE_TOL_M and er < POSE_TOL_RAD, (k, et, er)
+    assert st.relocalization_attempts >= 1 and info["attempts"] >= 1
+    assert abs(st.relocalization_attempts - info["attempts"]) <= 1 and abs(st.relocalizations - info["relocalizations"]) <= 1
+    ctx.close()
+
+
+def test_pipeline_against_the_reference_prune_rule(capsys):
+    """a12: RemovePointsFarFromLocation erases while it iterates (F/VoxelHashMap.cpp:178-186), so with tsl's
+    backward-shift deletion a far voxel can survive one extra scan; the oracle restates that with prune_mode=1, the
+    library implements the pure predicate.  220 HDL-64-shaped scans against BOTH oracle modes: poses within the bar
+    of the reference-rule run on every frame, and the survivors never change a correspondence count (they lie
+    beyond max_range of the sensor that left them behind)."""
+    ctx = api.Context(api.preset("kitti", max_points=1 << 17, map_capacity_log2=17))
+    pure, quirk = O.Slam(O.kitti_config()), O.Slam(O.kitti_config(prune_mode=1))
+    wt = wr = 0.0
+    survivors = scans_with = corr_differs = 0
+    for k in range(220):
+        xyzi, xyz, lab = _scan(k, "hdl64")
+        rg = ctx.process_scan_f32(xyzi, lab, None, "")
+        rp, rq = pure.process(xyz, lab), quirk.process(xyz, lab)
+        et, er = pose_err(rq["pose"], rg["pose"])
+        assert et < POSE_TOL_M and er < POSE_TOL_RAD, (k, et, er)
+        wt, wr = max(wt, et), max(wr, er)
+        assert rg["map_voxels"] == rp["map_voxels"] <= rq["map_voxels"]
+        survivors += rq["map_voxels"] - rp["map_voxels"]
+        scans_with += rq["map_voxels"] != rp["map_voxels"]
+        corr_differs += rq["correspondences"] != rp["correspondences"]
+        assert np.array_equal(rq["pose"], rp["pose"]), f"scan {k}: the prune rule changed the oracle's own pose"
+    ctx.close()
+    with capsys.disabled():
+        print(f"\n[prune rule, 220 scans] library vs reference-rule oracle: max pose diff {wt:.3e} m / {wr:.3e} rad; "
+              f"{survivors} surviving voxel-scans in {scans_with} scans; scans whose correspondence count changed: {corr_differs}")
+    assert corr_differs == 0 and scans_with > 0
