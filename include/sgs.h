@@ -267,6 +267,12 @@ int sgs_process_scan_f32_dev(sgs_ctx *ctx, const float *xyzi_dev, const int32_t 
  * Results are identical with or without the hint.  Ignored when cfg.deskew is set (a scan's deskew needs
  * the pose of the previous one).  No counterpart in the reference, whose mainProcess is strictly serial. */
 int sgs_prefetch_scan_f32_dev(sgs_ctx *ctx, const float *xyzi_dev, const int32_t *label_dev, int n, int is_kitti);
+/* The same hint for a scan still in HOST memory (the loader's buffers, ros/ros1/InsUtils.hpp:502-537): the H2D copy
+ * (about 2.4 MB for 120 000 points) is enqueued on the front stream and, when the buffers are pinned
+ * (hipHostMalloc / hipHostRegister), runs over PCIe while the current scan registers; pageable buffers work but
+ * copy synchronously.  The following sgs_process_scan_f32 call with the same (xyzi, label, n, is_kitti) picks the
+ * result up.  The buffers must stay valid and unchanged until that call returns. */
+int sgs_prefetch_scan_f32(sgs_ctx *ctx, const float *xyzi, const int32_t *label, int n, int is_kitti);
 /* Clouds of the last processed scan: which = 0 cropped, 1 cluster cloud (0.2 m), 2 frame_downsample,
  * 3 source.  xyz / label optional. */
 int sgs_get_cloud(sgs_ctx *ctx, int which, double *xyz, int32_t *label, int cap, int *n);

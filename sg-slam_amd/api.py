@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "sgs_voxel_keys", "sgs_voxel_downsample", "sgs_map_clear", "sgs_map_empty", "sgs_map_add_points",
     "sgs_map_update", "sgs_map_prune", "sgs_map_size", "sgs_map_pointcloud", "sgs_map_dump",
     "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_shard_set", "sgs_fast_icp", "sgs_graph_map_clear", "sgs_graph_map_track", "sgs_graph_map_instances", "sgs_graph_map_relocalize", "sgs_find_ins_match", "sgs_solve_svd", "sgs_ransac_alignment", "sgs_scan_descriptor", "sgs_gen_scan_descriptor", "sgs_cluster_points",
-    "sgs_build_graph", "sgs_process_scan", "sgs_process_scan_f32", "sgs_process_scan_f32_dev", "sgs_prefetch_scan_f32_dev", "sgs_get_cloud",
+    "sgs_build_graph", "sgs_process_scan", "sgs_process_scan_f32", "sgs_process_scan_f32_dev", "sgs_prefetch_scan_f32_dev", "sgs_prefetch_scan_f32", "sgs_get_cloud",
     "sgs_get_boxes", "sgs_get_poses", "sgs_remap_labels", "sgs_voxel_downsample_dev_noalloc",
 ]
 NOALLOC_MAX_POINTS = 131072  # SGS_NOALLOC_MAX_POINTS
@@ -135,6 +135,7 @@ def lib():
         L.sgs_process_scan_f32.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_int, ctypes.POINTER(SgsScanResult)]
         L.sgs_process_scan_f32_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_int, ctypes.POINTER(SgsScanResult)]
         L.sgs_prefetch_scan_f32_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_int]
+        L.sgs_prefetch_scan_f32.argtypes = [c_vp, c_vp, c_vp, c_int, c_int]
         L.sgs_get_cloud.argtypes = [c_vp, c_int, c_vp, c_vp, c_int, c_vp]
         L.sgs_get_boxes.argtypes = [c_vp, c_vp, c_int, c_vp]
         L.sgs_get_poses.argtypes = [c_vp, c_vp, c_int, c_vp]
@@ -474,6 +475,18 @@ class Context:
     def prefetch_scan_dev(self, xyzi_ptr, label_ptr, n, dataset=""):
         """Start the front half of the NEXT scan (device pointers) while the current one registers."""
         self._ck(lib().sgs_prefetch_scan_f32_dev(self.h, xyzi_ptr, label_ptr, int(n), int(dataset == "kitti")))
+
+    def process_scan_host(self, xyzi_ptr, label_ptr, n, dataset="", res=None):
+        """Host-pointer variant (ints: addresses of float32 n x 4 / int32 n buffers, pinned or not); raw SgsScanResult."""
+        if res is None:
+            res = SgsScanResult()
+        res.size = ctypes.sizeof(SgsScanResult)
+        self._ck(lib().sgs_process_scan_f32(self.h, xyzi_ptr, label_ptr, int(n), None, int(dataset == "kitti"), ctypes.byref(res)))
+        return res
+
+    def prefetch_scan_host(self, xyzi_ptr, label_ptr, n, dataset=""):
+        """Start the H2D copy + front half of the NEXT scan (host pointers) while the current one registers."""
+        self._ck(lib().sgs_prefetch_scan_f32(self.h, xyzi_ptr, label_ptr, int(n), int(dataset == "kitti")))
 
     def cloud(self, which):
         n = c_int()

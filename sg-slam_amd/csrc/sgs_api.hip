@@ -653,16 +653,41 @@ struct FrontInput {
     int n, is_kitti;
     bool deskew;
     double delta[6];
+    // host sources (nullable): copied into the context's staging buffers on the front stream, inside the same
+    // critical section as the kernels that read them (the staging buffers are shared by every front)
+    const float *h_f32 = nullptr;
+    const double *h_f64 = nullptr;
+    const int32_t *h_label = nullptr;
+    const double *h_ts = nullptr;
 };
 
-int enqueue_front(sgs_ctx *c, ScanSet &S, const FrontInput &in) {
+int enqueue_front(sgs_ctx *c, ScanSet &S, const FrontInput &in_) {
     // the kernels of one front must be contiguous on the front stream: they share its scratch tables
     std::lock_guard<std::mutex> front_lock(c->front_mu);
     hipStream_t f = c->streamF;
     const sgs_config &cfg = c->cfg;
-    const int n = in.n;
+    const int n = in_.n;
     // the set may still be read by the map update of the scan before last
     if (S.free_recorded) SGS_HIP(c, hipStreamWaitEvent(f, S.ev_free, 0));
+    FrontInput in = in_;
+    if (n > 0) {  // host input: H2D on the front stream (pinned host memory makes it overlap the registration stream)
+        if (in.h_f32) {
+            SGS_HIP(c, hipMemcpyAsync(c->in_f32, in.h_f32, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, f));
+            in.d_f32 = c->in_f32;
+        }
+        if (in.h_f64) {
+            SGS_HIP(c, hipMemcpyAsync(c->in_f64, in.h_f64, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, f));
+            in.d_f64 = c->in_f64;
+        }
+        if (in.h_label) {
+            SGS_HIP(c, hipMemcpyAsync(c->in_label, in.h_label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, f));
+            in.d_label = c->in_label;
+        }
+        if (in.h_ts) {
+            SGS_HIP(c, hipMemcpyAsync(c->in_ts, in.h_ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, f));
+            in.d_ts = c->in_ts;
+        }
+    }
     if (c->profiling && c->stage_ev_ok) hipEventRecord(c->stage_ev[0], f);
     // ---- deskew / KITTI correction / crop (P/SemGraphSLAM.cpp:18-36)
     PreParams p{};
@@ -776,8 +801,22 @@ GraphBuilder graph_builder(sgs_ctx *c) {
     return [c](const double *boxes, int nb, GraphData *out) { return build_graph_data(c, boxes, nb, out); };
 }
 
-int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const int32_t *d_label, int n,
-                     const double *d_ts, int is_kitti, sgs_scan_result *res) {
+// where a scan comes from: device pointers (d_*) or host pointers (h_*, copied by the front half)
+struct ScanSource {
+    const float *d_f32 = nullptr;
+    const double *d_f64 = nullptr;
+    const int32_t *d_label = nullptr;
+    const double *d_ts = nullptr;
+    const float *h_f32 = nullptr;
+    const double *h_f64 = nullptr;
+    const int32_t *h_label = nullptr;
+    const double *h_ts = nullptr;
+    const void *key_xyz() const { return d_f32 ? (const void *)d_f32 : d_f64 ? (const void *)d_f64 : h_f32 ? (const void *)h_f32 : (const void *)h_f64; }
+    const void *key_label() const { return d_label ? (const void *)d_label : (const void *)h_label; }
+    bool has_ts() const { return d_ts || h_ts; }
+};
+
+int process_scan_dev(sgs_ctx *c, const ScanSource &src, int n, int is_kitti, sgs_scan_result *res) {
     if (n < 0 || n > c->N) return fail(c, SGS_ECAPACITY, "scan of %d points exceeds max_points=%d", n, c->N);
     const double t_call0 = now_ms();
     hipStream_t s = c->stream;
@@ -785,9 +824,9 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
     // ---- front half: already under way when this scan was prefetched.  Between a hint for scan k+1 and
     // the call for scan k both sets can hold a prefetched scan; take the one that matches, else a free one.
     {
-        const void *kx = d_f32 ? (const void *)d_f32 : (const void *)d_f64;
+        const void *kx = src.key_xyz(), *kl = src.key_label();
         auto matches = [&](const ScanSet &N) {
-            return N.prefetched && N.key_xyz == kx && N.key_label == (const void *)d_label && N.key_n == n && N.key_kitti == is_kitti;
+            return N.prefetched && N.key_xyz == kx && N.key_label == kl && N.key_n == n && N.key_kitti == is_kitti;
         };
         if (matches(c->sets[c->cur ^ 1])) c->cur ^= 1;
         else if (!matches(c->sets[c->cur])) {
@@ -801,8 +840,9 @@ int process_scan_dev(sgs_ctx *c, const float *d_f32, const double *d_f64, const 
         while (!S.front_enqueued.load(std::memory_order_acquire)) __builtin_ia32_pause();
         if (S.front_rc) return S.front_rc;
     } else {
-        FrontInput in{d_f32, d_f64, d_label, d_ts, n, is_kitti, false, {0, 0, 0, 0, 0, 0}};
-        if (cfg.deskew && d_ts && c->poses.size() > 2) {
+        FrontInput in{src.d_f32, src.d_f64, src.d_label, src.d_ts, n, is_kitti, false, {0, 0, 0, 0, 0, 0}};
+        in.h_f32 = src.h_f32; in.h_f64 = src.h_f64; in.h_label = src.h_label; in.h_ts = src.h_ts;
+        if (cfg.deskew && src.has_ts() && c->poses.size() > 2) {
             const size_t N = c->poses.size();
             in.deskew = true;
             rigid_log(compose(invert(c->poses[N - 2]), c->poses[N - 1]), in.delta);
@@ -1808,32 +1848,33 @@ int sgs_process_scan(sgs_ctx *c, const double *xyz, const int32_t *label, int n,
     ENTER_NOSETTLE(c);
     CHECK_N(c, n);
     if (n && (!xyz || !label)) return fail(c, SGS_EINVAL, "null argument");
-    SGS_HIP(c, hipMemcpyAsync(c->in_f64, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
-    SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
-    if (ts) SGS_HIP(c, hipMemcpyAsync(c->in_ts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
-    return process_scan_dev(c, nullptr, c->in_f64, c->in_label, n, ts ? c->in_ts : nullptr, is_kitti, res);
+    ScanSource src;
+    src.h_f64 = xyz; src.h_label = label; src.h_ts = ts;  // copied on the front stream, by the front half itself
+    const int r = process_scan_dev(c, src, n, is_kitti, res);
+    // the caller may reuse its buffers when the call returns: the copies sit at the head of the front half, which the
+    // registration waited for; a prefetched front was synchronised the same way
+    return r;
 }
 int sgs_process_scan_f32(sgs_ctx *c, const float *xyzi, const int32_t *label, int n, const double *ts, int is_kitti,
                          sgs_scan_result *res) {
     ENTER_NOSETTLE(c);
     CHECK_N(c, n);
     if (n && (!xyzi || !label)) return fail(c, SGS_EINVAL, "null argument");
-    SGS_HIP(c, hipMemcpyAsync(c->in_f32, xyzi, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
-    SGS_HIP(c, hipMemcpyAsync(c->in_label, label, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
-    if (ts) SGS_HIP(c, hipMemcpyAsync(c->in_ts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->streamF));  // the front half reads them on its own stream
-    return process_scan_dev(c, c->in_f32, nullptr, c->in_label, n, ts ? c->in_ts : nullptr, is_kitti, res);
+    ScanSource src;
+    src.h_f32 = xyzi; src.h_label = label; src.h_ts = ts;
+    return process_scan_dev(c, src, n, is_kitti, res);
 }
 int sgs_process_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *label_dev, int n, const double *ts_dev,
                              int is_kitti, sgs_scan_result *res) {
     ENTER_NOSETTLE(c);
     CHECK_N(c, n);
     if (n && (!xyzi_dev || !label_dev)) return fail(c, SGS_EINVAL, "null argument");
-    return process_scan_dev(c, xyzi_dev, nullptr, label_dev, n, ts_dev, is_kitti, res);
+    ScanSource src;
+    src.d_f32 = xyzi_dev; src.d_label = label_dev; src.d_ts = ts_dev;
+    return process_scan_dev(c, src, n, is_kitti, res);
 }
-int sgs_prefetch_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *label_dev, int n, int is_kitti) {
-    ENTER_NOSETTLE(c);
-    CHECK_N(c, n);
-    if (n && (!xyzi_dev || !label_dev)) return fail(c, SGS_EINVAL, "null argument");
+namespace {
+int prefetch_common(sgs_ctx *c, const ScanSource &src, int n, int is_kitti) {
     if (c->cfg.deskew) return SGS_OK;  // the deskew of a scan needs the pose of the one before it: nothing to run ahead
     if (c->cfg.relocalization_enable && c->cfg.enable_graph) return SGS_OK;  // the tracked-instance map is updated scan by scan
     // the set that holds no pending hint: normally the one whose scan the caller has just finished with
@@ -1841,21 +1882,39 @@ int sgs_prefetch_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *
     if (N.prefetched) return SGS_OK;  // two hints already pending: ignore this one
     wait_set_job(N);
     N.prefetched = true;
-    N.key_xyz = xyzi_dev; N.key_label = label_dev; N.key_n = n; N.key_kitti = is_kitti;
+    N.key_xyz = src.key_xyz(); N.key_label = src.key_label(); N.key_n = n; N.key_kitti = is_kitti;
     N.front_enqueued.store(0, std::memory_order_relaxed);
     N.job_done.store(0, std::memory_order_relaxed);
     N.front_rc = SGS_OK;
     ScanSet *ps = &N;
     const int slot = (int)(ps - c->sets);
     const bool graph = c->cfg.enable_graph != 0;
-    c->gworker.submit([c, ps, slot, xyzi_dev, label_dev, n, is_kitti, graph] {
-        const FrontInput in{xyzi_dev, nullptr, label_dev, nullptr, n, is_kitti, false, {0, 0, 0, 0, 0, 0}};
+    c->gworker.submit([c, ps, slot, src, n, is_kitti, graph] {
+        FrontInput in{src.d_f32, nullptr, src.d_label, nullptr, n, is_kitti, false, {0, 0, 0, 0, 0, 0}};
+        in.h_f32 = src.h_f32; in.h_label = src.h_label;
         ps->front_rc = enqueue_front(c, *ps, in);
         ps->front_enqueued.store(1, std::memory_order_release);
         if (graph && !ps->front_rc) graph_enqueue_job(c, *ps, slot, n);  // hands over to the second helper
         else ps->job_done.store(1, std::memory_order_release);
     });
     return SGS_OK;
+}
+}  // namespace
+int sgs_prefetch_scan_f32_dev(sgs_ctx *c, const float *xyzi_dev, const int32_t *label_dev, int n, int is_kitti) {
+    ENTER_NOSETTLE(c);
+    CHECK_N(c, n);
+    if (n && (!xyzi_dev || !label_dev)) return fail(c, SGS_EINVAL, "null argument");
+    ScanSource src;
+    src.d_f32 = xyzi_dev; src.d_label = label_dev;
+    return prefetch_common(c, src, n, is_kitti);
+}
+int sgs_prefetch_scan_f32(sgs_ctx *c, const float *xyzi, const int32_t *label, int n, int is_kitti) {
+    ENTER_NOSETTLE(c);
+    CHECK_N(c, n);
+    if (n && (!xyzi || !label)) return fail(c, SGS_EINVAL, "null argument");
+    ScanSource src;
+    src.h_f32 = xyzi; src.h_label = label;
+    return prefetch_common(c, src, n, is_kitti);
 }
 int sgs_get_cloud(sgs_ctx *c, int which, double *xyz, int32_t *label, int cap, int *n) {
     ENTER(c);

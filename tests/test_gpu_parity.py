@@ -1329,3 +1329,30 @@ def test_pipeline_against_the_reference_prune_rule(capsys):
         print(f"\n[prune rule, 220 scans] library vs reference-rule oracle: max pose diff {wt:.3e} m / {wr:.3e} rad; "
               f"{survivors} surviving voxel-scans in {scans_with} scans; scans whose correspondence count changed: {corr_differs}")
     assert corr_differs == 0 and scans_with > 0
+
+
+def test_pipeline_host_prefetch_matches_serial():
+    """sgs_prefetch_scan_f32 (host pointers: H2D + front half of the next scan early) against the plain serial calls:
+    bit-identical poses, sizes and maps - with correct hints, wrong hints and no hints, pageable host buffers."""
+    frames = 20
+    scans = [_scan(k, "small") for k in range(frames)]
+    hx = [np.ascontiguousarray(s[0], dtype=np.float32) for s in scans]
+    hl = [np.ascontiguousarray(s[2], dtype=np.int32) for s in scans]
+    a, b = make_ctx(async_map_update=1), make_ctx()
+    for k in range(frames):
+        n = len(hl[k])
+        if k + 1 < frames and k % 7 != 3:
+            nxt = k + 1 if k % 5 != 2 else k
+            a.prefetch_scan_host(hx[nxt].ctypes.data, hl[nxt].ctypes.data, len(hl[nxt]), "")
+        ra = a.process_scan_host(hx[k].ctypes.data, hl[k].ctypes.data, n)
+        rb = b.process_scan_f32(hx[k], hl[k], None, "")
+        assert list(ra.pose) == list(rb["pose"]) and ra.icp_iterations == rb["iterations"], k
+        assert (ra.n_in, ra.n_cluster, ra.n_ds, ra.n_src, ra.n_boxes) == (rb["n_in"], rb["n_cluster"], rb["n_ds"], rb["n_src"], rb["n_boxes"])
+        if k % 4 == 1:
+            assert np.array_equal(a.boxes(), b.boxes())
+            assert np.array_equal(a.cloud(3)[0], b.cloud(3)[0])
+    ka, ca, pa = a.map_dump()
+    kb, cb, pb = b.map_dump()
+    assert np.array_equal(ka, kb) and np.array_equal(ca, cb) and np.array_equal(pa, pb)
+    a.close()
+    b.close()
