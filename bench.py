@@ -159,7 +159,7 @@ def main():
     out = {
         "metric": "scans/sec (120k-pt HDL-64 scan-to-map ICP)", "value": round(value, 2), "unit": "scans/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 keys/accumulation + f32 candidate distances",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "synthetic HDL-64-shaped scans (64x1875 = 120000 rays, 20 classes), voxel 1.0 m, max 20 pts/voxel, "
                                "frame-by-frame odometry + semantic graph, one scan stream per GPU (BASELINE.json configs[1])",

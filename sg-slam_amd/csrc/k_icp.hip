@@ -17,6 +17,7 @@
 // accumulated in fp64 per wave, combined per block through LDS in fixed order, written as per-block
 // partials and folded by the solve kernel in fixed order: bit-reproducible run to run, no atomics.
 // This is gather/latency bound integer + fp work; there is no dense contraction, hence no MFMA.
+#include <algorithm>
 #include <climits>
 #include <type_traits>
 
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_iteration_kernel(MapView m, C
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int waves_per_block = kIcpThreads / 64;
     if (st->icp_done) return;
-    const int n = *n_ptr;
+    const int n = min(max(*n_ptr, 0), src_cap);  // never index past the cloud, whatever the size word holds
     const int q0 = blockIdx.x * waves_per_block + wave, stride = gridDim.x * waves_per_block;
     const int ql = icp_lane_query(q0 < src_cap ? q0 : src_cap - 1, stride, n, lane);
     const D3 p0{src.x[ql], src.y[ql], src.z[ql]};
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(kIcpThreads, SGS_ICP_MIN_WAVES) void icp_persistent
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int waves_per_block = kIcpThreads / 64;
     const int q0 = blockIdx.x * waves_per_block + wave, stride = gridDim.x * waves_per_block;
-    const int n = *n_ptr;
+    const int n = min(max(*n_ptr, 0), src_cap);  // never index past the cloud, whatever the size word holds
     // the wave's first query - or first two, one per half of the wave - stays in registers for the whole loop
     const int ql = icp_lane_query(q0 < src_cap ? q0 : src_cap - 1, stride, n, lane);
     const D3 p0{src.x[ql], src.y[ql], src.z[ql]};
@@ -630,8 +631,10 @@ __global__ __launch_bounds__(kIcpThreads, SGS_ICP_MIN_WAVES) void icp_persistent
     if (mirror && blockIdx.x == 0 && threadIdx.x == 0) mirror->t_icp_start = wall_clock64();
     // the registration state: left in DevState by icp_init_kernel, or - a launch chained behind a map update, with
     // no dispatch in between - written into the host mirror by the host
-    const bool host_init = mirror && mirror->init_enabled != 0;
-    if (host_init && mirror->init_enabled == 2) {  // test hook (SGS_TEST_ABORT_EVERY): behave as if the inter-block wait ran out
+    const int init_mode = mirror ? mirror->init_enabled : 0;
+    const bool host_init = init_mode != 0;
+    if (host_init && init_mode != 1) {  // 2 = test hook (SGS_TEST_ABORT_EVERY): behave as if the inter-block wait ran out;
+                                        // anything else is a corrupted mailbox: give up the same way, the host repeats the slow way
         if (threadIdx.x == 0 && blockIdx.x == 0) {  // ONE place publishes the decision: block 0
             st->icp_abort = 1;
             __hip_atomic_store(&mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -787,9 +790,11 @@ __global__ __launch_bounds__(kIcpThreads, SGS_ICP_MIN_WAVES) void icp_persistent
     }
     if (lane != 0) return;
     const long long corr = s_cnt[0], cand = s_cnt[1], probe = s_cnt[2];
-    if (mirror && mirror->init_enabled != 0) {  // what icp_init_kernel would have left
-        const int32_t *z = mirror->init_sizes4;
-        if (z) { st->n_in = z[0]; st->n_c = z[1]; st->n_d = z[2]; st->n_s = z[3]; }
+    if (host_init) {  // what icp_init_kernel would have left
+        // a host-initialised launch registers a ScanSet's source cloud: n_ptr is word 3 of that set's device int32[4]
+        // {n_in, n_c, n_d, n_s} (no device pointer travels through the host-mapped mailbox)
+        const int32_t *z = n_ptr - 3;
+        st->n_in = z[0]; st->n_c = z[1]; st->n_d = z[2]; st->n_s = z[3];
         st->max_corr = max_corr; st->kernel_th = th; st->icp_max_iter = max_iter;
     }
     st->T_icp = s_T[0];
@@ -888,6 +893,19 @@ void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap,
     else
         hipLaunchKernelGGL(icp_persistent_kernel<false>, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, m, src, src_cap, n_ptr, st,
                            partials2, tickets, mirror);
+}
+
+// Can all kIcpBlocks blocks of the one-launch loop be resident at once on this device?  Its inter-block wait
+// assumes so (it is not a cooperative launch): on a smaller or partitioned device the caller must use one launch
+// per iteration instead of finding out through the 2-second spin limit.
+bool icp_persistent_fits(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+    int per_cu_a = 0, per_cu_b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, icp_persistent_kernel<false>, kIcpThreads, 0) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, icp_persistent_kernel<true>, kIcpThreads, 0) != hipSuccess) return false;
+    const long resident = (long)std::min(per_cu_a, per_cu_b) * prop.multiProcessorCount;
+    return resident >= kIcpBlocks;
 }
 
 namespace {

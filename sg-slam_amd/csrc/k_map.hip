@@ -190,7 +190,9 @@ __global__ __launch_bounds__(kCensusBlock) void map_census_kernel(const int4 *__
             mirror->map_points = p;
             mirror->map_err_flags = st->err_flags;
             mirror->t_census_end = wall_clock64();
-            __hip_atomic_store(&mirror->census_seq, mirror->census_seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const int32_t seq = st->census_seq + 1;  // counted in device memory: the host-mapped mirror is write-only for kernels
+            st->census_seq = seq;
+            __hip_atomic_store(&mirror->census_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -501,7 +501,7 @@ int icp_persistent_launch(sgs_ctx *c, CloudView src, const int32_t *n_ptr, const
         mi->init_guess[4] = hi->guess.t.x; mi->init_guess[5] = hi->guess.t.y; mi->init_guess[6] = hi->guess.t.z;
         mi->init_max_corr = hi->max_corr; mi->init_kernel_th = hi->kernel_th;
         mi->init_max_iter = kIcpMaxIter;
-        mi->init_sizes4 = hi->sizes4;
+        if (hi->sizes4 + 3 != n_ptr) return fail(c, SGS_EINVAL, "host-initialised launch: n_ptr must be word 3 of the scan's size block");
         mi->init_ticket_base = c->ticket_base;
         mi->init_enabled = 1;
         if (c->test_abort_every > 0 && ++c->test_abort_count % c->test_abort_every == 0) mi->init_enabled = 2;
@@ -1175,7 +1175,8 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     if ((r = dev_alloc(c, &c->partials, 2 * (size_t)kIcpBlocks * kIcpSums))) return bail(r);
     {
         const char *e = getenv("SGS_ICP_PER_LAUNCH");
-        c->icp_persistent = !(e && e[0] == '1');
+        // the one-launch loop waits for its other blocks: only where all of them fit the device at once
+        c->icp_persistent = !(e && e[0] == '1') && icp_persistent_fits(device);
         const char *ab = getenv("SGS_TEST_ABORT_EVERY");
         c->test_abort_every = ab ? atoi(ab) : 0;
         const char *t = getenv("SGS_TRACE");

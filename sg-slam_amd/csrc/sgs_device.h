@@ -89,6 +89,7 @@ struct DevState {
     // map
     int32_t map_live, map_tomb, map_points;
     int32_t icp_abort;  // set by the one-launch loop when its inter-block wait ran out, cleared by icp_init
+    int32_t census_seq; // map sweeps so far (mirrored to the host)
     long long cas_retries;
 };
 
@@ -112,7 +113,7 @@ struct HostMirror {
     uint32_t init_ticket_base, pad3;  // iterations already counted on the arrival counters (they are not re-zeroed)
     double init_guess[7];             // qw, qx, qy, qz, tx, ty, tz
     double init_max_corr, init_kernel_th;
-    const int32_t *init_sizes4;       // device int32[4] of the scan: n_in, n_c, n_d, n_s
+    unsigned long long init_reserved; // (was a device pointer: the kernel now derives the scan's size words from its n_ptr argument)
     // device timestamps (wall_clock64, 100 MHz) for SGS_TRACE=1: start / end of the one-launch Gauss-Newton
     // kernel and end of the map update's census kernel
     unsigned long long t_icp_start, t_icp_end, t_census_end;
@@ -167,6 +168,7 @@ void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap /
 // launch_icp_iteration)
 void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
                            double *partials2, uint32_t *tickets, HostMirror *mirror);
+bool icp_persistent_fits(int device);  // all kIcpBlocks blocks of the one-launch loop resident at once on this device?
 void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const Rigid &T_total, int iter, long long corr);
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,
                             int32_t *found);
