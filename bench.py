@@ -42,6 +42,10 @@ def main():
     ap.add_argument("--sync-map-update", action="store_true",
                     help="wait for each scan's local-map update before the step returns (default: async_map_update=1, the "
                          "update overlaps the next step's preprocessing; all of it is inside the timed region either way)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="extra leg at N=1 (off by default: the entry point is experimental, DESIGN 6): this many independent scan "
+                         "sequences on the ONE GPU stepped together through sgs_process_scans_batched_f32_dev (one registration launch "
+                         "for all of them), aggregate scans/s reported as `multi_stream_batched`.  Never the headline value")
     ap.add_argument("--streams", type=int, default=2,
                     help="extra leg at N=1: this many independent scan streams (one context + one host thread each) on the ONE "
                          "GPU, aggregate scans/s reported as `multi_stream` (SURVEY.md 8d); 0 = skip.  Never the headline value")
@@ -234,8 +238,53 @@ def main():
         fallbacks = sum(c.stats().icp_fallbacks for c in ctxs)
         [c.close() for c in ctxs]
         out["multi_stream"] = {"streams": S, "scans_per_stream": Km, "value": round(S * Km / el, 2), "unit": "scans/s",
-                               "per_stream": round(Km / el, 2), "icp_one_launch_fallbacks": int(fallbacks),
-                               "all_streams_same_pose_as_single": bool(all(np.array_equal(last[k], poses[W + Km - 1]) for k in range(S)))}
+                                        "per_stream": round(Km / el, 2), "icp_one_launch_fallbacks": int(fallbacks),
+                                        "all_streams_same_pose_as_single": bool(all(np.array_equal(last[k], poses[W + Km - 1]) for k in range(S))),
+                                        "note": "independent contexts, one host thread each, no shared launch: they do not add up (DESIGN 6)"}
+
+    if rank == 0 and world == 1 and args.batch > 0:
+        # several scan sequences per GPU the way that does add up: ONE registration launch steps the Gauss-Newton loops of all
+        # sequences in lockstep (sgs_process_scans_batched_f32_dev); every sequence still runs the whole per-scan path, and
+        # its poses are bit-identical to the single-sequence run above.  Sequence s replays the same drive from scan s on
+        # (different scans in flight at any moment), one host thread drives them all.
+        def batched_leg(S, Km):
+            cfg = api.preset("kitti", max_points=max(1 << 17, 1 << int(np.ceil(np.log2(n_pts)))), map_capacity_log2=args.map_log2,
+                             enable_graph=0 if args.no_graph else 1, async_map_update=1)
+            ctxs = [api.Context(cfg, device=local_rank) for _ in range(S)]
+            batch = api.Batch(ctxs)
+            xs = [t.data_ptr() for t in d_scans]
+            ls = [t.data_ptr() for t in d_labels]
+            ns = [n_pts] * S
+            span = total - S  # scans every sequence can play
+            Wb, Kb = min(W, span // 4), 0
+            Kb = min(Km, span - Wb)
+            bposes = np.zeros((S, Wb + Kb, 7))
+
+            def one(i):
+                if not args.no_prefetch and i + 1 < Wb + Kb:
+                    for q in range(S):
+                        ctxs[q].prefetch_scan_dev(xs[q + i + 1], ls[q + i + 1], n_pts, "")
+                res = batch.process([xs[q + i] for q in range(S)], [ls[q + i] for q in range(S)], ns)
+                for q in range(S):
+                    bposes[q, i] = res[q].pose[:]
+            for i in range(Wb):
+                one(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(Wb, Wb + Kb):
+                one(i)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            fallbacks = sum(c.stats().icp_fallbacks for c in ctxs)
+            [c.close() for c in ctxs]
+            # sequence 0 plays exactly the scans of the single-sequence pass: its poses must be the same bits
+            same = bool(np.array_equal(bposes[0], poses[:Wb + Kb]))
+            return {"streams": S, "scans_per_stream": Kb, "warmup_per_stream": Wb, "value": round(S * Kb / el, 2), "unit": "scans/s",
+                    "per_stream": round(Kb / el, 2), "ms_per_step_of_all_streams": round(1e3 * el / Kb, 4),
+                    "icp_one_launch_fallbacks": int(fallbacks), "sequence0_same_poses_as_single_stream": same,
+                    "mode": "sgs_process_scans_batched_f32_dev: one registration launch per step for all sequences"}
+        out["multi_stream_batched"] = batched_leg(args.batch, min(K, 150))
+        out["multi_stream_batched"]["vs_single_stream"] = round(out["multi_stream_batched"]["value"] / value, 3)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -273,6 +273,18 @@ int sgs_prefetch_scan_f32_dev(sgs_ctx *ctx, const float *xyzi_dev, const int32_t
  * copy synchronously.  The following sgs_process_scan_f32 call with the same (xyzi, label, n, is_kitti) picks the
  * result up.  The buffers must stay valid and unchanged until that call returns. */
 int sgs_prefetch_scan_f32(sgs_ctx *ctx, const float *xyzi, const int32_t *label, int n, int is_kitti);
+/* One step of S independent scan sequences on ONE GPU (SURVEY.md 5 "many-per-GPU"; no counterpart in the reference, whose
+ * mainProcess serves one sequence): ctxs[s] is the context of sequence s, (xyzi_dev[s], label_dev[s], n[s]) its next scan in
+ * device memory.  Does for every sequence what sgs_process_scan_f32_dev does with cfg.async_map_update = 1 - same poses,
+ * clouds, boxes and maps, bit for bit - but registers all S scans in ONE launch that steps their Gauss-Newton loops in
+ * lockstep (the arrival / fold / solve part of an iteration, ~70 % of it for one sequence, is paid once for up to four
+ * sequences), then runs each context's map update on that context's own stream.  A single sequence cannot fill the
+ * GPU (a scan is a chain of ~13 dependent iterations over ~1 000 queries); S sequences side by side can.  Hints for the
+ * following scans go through sgs_prefetch_scan_f32_dev per context, as before.  1 <= S <= 8, all contexts on one device,
+ * distinct, not sharded / profiled / deskewing / relocalizing (those take the single-sequence entry points).  results: S
+ * entries (nullable).  Errors are reported on ctxs[0] (sgs_last_error(ctxs[0])). */
+int sgs_process_scans_batched_f32_dev(sgs_ctx *const *ctxs, int S, const float *const *xyzi_dev, const int32_t *const *label_dev,
+                                      const int *n, int is_kitti, sgs_scan_result *results);
 /* Clouds of the last processed scan: which = 0 cropped, 1 cluster cloud (0.2 m), 2 frame_downsample,
  * 3 source.  xyz / label optional. */
 int sgs_get_cloud(sgs_ctx *ctx, int which, double *xyz, int32_t *label, int cap, int *n);

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "sgs_voxel_keys", "sgs_voxel_downsample", "sgs_map_clear", "sgs_map_empty", "sgs_map_add_points",
     "sgs_map_update", "sgs_map_prune", "sgs_map_size", "sgs_map_pointcloud", "sgs_map_dump",
     "sgs_map_get_correspondences", "sgs_build_linear_system", "sgs_register_frame", "sgs_shard_set", "sgs_fast_icp", "sgs_graph_map_clear", "sgs_graph_map_track", "sgs_graph_map_instances", "sgs_graph_map_relocalize", "sgs_find_ins_match", "sgs_solve_svd", "sgs_ransac_alignment", "sgs_scan_descriptor", "sgs_gen_scan_descriptor", "sgs_cluster_points",
-    "sgs_build_graph", "sgs_process_scan", "sgs_process_scan_f32", "sgs_process_scan_f32_dev", "sgs_prefetch_scan_f32_dev", "sgs_prefetch_scan_f32", "sgs_get_cloud",
+    "sgs_build_graph", "sgs_process_scan", "sgs_process_scan_f32", "sgs_process_scan_f32_dev", "sgs_prefetch_scan_f32_dev", "sgs_prefetch_scan_f32", "sgs_process_scans_batched_f32_dev", "sgs_get_cloud",
     "sgs_get_boxes", "sgs_get_poses", "sgs_remap_labels", "sgs_voxel_downsample_dev_noalloc",
 ]
 NOALLOC_MAX_POINTS = 131072  # SGS_NOALLOC_MAX_POINTS
@@ -136,6 +136,7 @@ def lib():
         L.sgs_process_scan_f32_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_int, ctypes.POINTER(SgsScanResult)]
         L.sgs_prefetch_scan_f32_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_int]
         L.sgs_prefetch_scan_f32.argtypes = [c_vp, c_vp, c_vp, c_int, c_int]
+        L.sgs_process_scans_batched_f32_dev.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp]
         L.sgs_get_cloud.argtypes = [c_vp, c_int, c_vp, c_vp, c_int, c_vp]
         L.sgs_get_boxes.argtypes = [c_vp, c_vp, c_int, c_vp]
         L.sgs_get_poses.argtypes = [c_vp, c_vp, c_int, c_vp]
@@ -211,6 +212,30 @@ def remap_labels(raw):
     if r != SGS_OK:
         raise SgsError(r, "sgs_remap_labels")
     return out
+
+
+class Batch:
+    """S contexts (one scan sequence each) on one GPU, stepped together: sgs_process_scans_batched_f32_dev."""
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+        S = len(self.ctxs)
+        self._h = (c_vp * S)(*[c.h for c in self.ctxs])
+        self._x = (c_vp * S)()
+        self._l = (c_vp * S)()
+        self._n = (c_int * S)()
+        self.results = (SgsScanResult * S)()
+
+    def process(self, xyzi_ptrs, label_ptrs, ns, dataset=""):
+        """Device pointers (ints) of every sequence's next scan; returns the ctypes array of S SgsScanResult."""
+        S = len(self.ctxs)
+        for s in range(S):
+            self._x[s] = xyzi_ptrs[s]; self._l[s] = label_ptrs[s]; self._n[s] = int(ns[s])
+            self.results[s].size = ctypes.sizeof(SgsScanResult)
+        r = lib().sgs_process_scans_batched_f32_dev(self._h, S, self._x, self._l, self._n, int(dataset == "kitti"), self.results)
+        if r != SGS_OK:
+            raise SgsError(r, lib().sgs_last_error(self.ctxs[0].h).decode())
+        return self.results
 
 
 class Context:

@@ -815,6 +815,205 @@ __global__ __launch_bounds__(kIcpThreads, SGS_ICP_MIN_WAVES) void icp_persistent
     }
 }
 
+// ---- the Gauss-Newton loops of SEVERAL independent scan sequences in ONE launch, in lockstep ------------------
+// A single sequence leaves the chip idle most of the time: an iteration is ~3 us of per-query work and ~7 us of
+// arrival / fold / solve that do not depend on the scan.  Here every iteration runs the accumulate phase of each
+// still-active sequence back to back (same wave <-> query mapping as the single-sequence kernel), ONE arrival for all
+// of them, and then wave w of every block folds and solves sequences w, w + 4, ... side by side, so the fixed part
+// is paid once per iteration for up to four sequences.  Every block again computes every new pose itself, bit for
+// bit the same, and the arithmetic of a sequence (per-wave sums, per-block order, fold order, solve) is exactly
+// that of icp_persistent_kernel: a batched registration returns the same bits as a single one.
+// A sequence leaves the lockstep when it has converged (or was flagged `skip`: empty map, F/Registration.cpp:152).
+struct BatchDev {       // device-side word of a batch engine
+    int32_t abort;      // the launch gave up (inter-block wait ran out): queued map updates skip themselves
+};
+
+constexpr int kBatchFoldRows = 5;  // rows of partials a wave folds per round trip (20 loads in flight per lane)
+
+// one wave folds all kIcpSums rows of one sequence's partials ([scalar][block]); same per-row order as fold_partials
+__device__ inline void fold_partials_one_wave(const double *partials, double *out /*shared [kIcpSums]*/, int lane) {
+    constexpr int kCols = kIcpBlocks / 64;
+    static_assert(kIcpSums % kBatchFoldRows == 0, "whole rounds");
+#pragma unroll 1
+    for (int r0 = 0; r0 < kIcpSums; r0 += kBatchFoldRows) {
+        double v[kBatchFoldRows][kCols];
+#pragma unroll
+        for (int r = 0; r < kBatchFoldRows; ++r)
+#pragma unroll
+            for (int c = 0; c < kCols; ++c)
+                v[r][c] = __hip_atomic_load(&partials[(size_t)(r0 + r) * kIcpBlocks + c * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < kBatchFoldRows; ++r) {
+            double sum = v[r][0];
+#pragma unroll
+            for (int c = 1; c < kCols; ++c) sum += v[r][c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+            if (lane == 0) out[r0 + r] = sum;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kIcpThreads, SGS_ICP_MIN_WAVES) void icp_batched_kernel(BatchArgs A, double *partials2 /*[2][kIcpMaxBatch][kIcpSums][kIcpBlocks]*/,
+                                                                                   uint32_t *tickets, BatchDev *bdev) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int waves_per_block = kIcpThreads / 64;
+    const int q0 = blockIdx.x * waves_per_block + wave, stride = gridDim.x * waves_per_block;
+    const int S = A.S;
+    __shared__ double red[kIcpMaxBatch][kIcpThreads / 64][2][kIcpSums];
+    __shared__ double Ssum[kIcpMaxBatch][kIcpSums];
+    __shared__ double solve_x[kIcpThreads / 64][6];
+    __shared__ Rigid s_T[kIcpMaxBatch][2];        // [0] T_icp, [1] T_total
+    __shared__ long long s_cnt[kIcpMaxBatch][3];  // correspondences, candidates, probes
+    __shared__ int s_it[kIcpMaxBatch];            // iterations run
+    __shared__ int s_done[kIcpMaxBatch];
+    __shared__ int s_flag;
+    if (threadIdx.x < S) {
+        const int s = threadIdx.x;
+        s_T[s][0] = rigid_identity();
+        s_T[s][1] = A.seq[s].guess;
+        s_cnt[s][0] = s_cnt[s][1] = s_cnt[s][2] = 0;
+        s_it[s] = 0;
+        s_done[s] = A.seq[s].skip ? 1 : 0;
+    }
+    if (A.trace && blockIdx.x == 0 && threadIdx.x == 0) A.seq[0].mirror->t_icp_start = wall_clock64();
+    __syncthreads();
+    int it = 0;
+    while (it < A.max_iter) {
+        // ---- accumulate: every active sequence, one after the other
+        bool any = false;
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            if (s_done[s]) continue;
+            any = true;
+            const BatchSeq &Q = A.seq[s];
+            const int n = min(max(*Q.n_ptr, 0), Q.src_cap);
+            const Rigid T_total = s_T[s][1];
+            const int ql = icp_lane_query(q0 < Q.src_cap ? q0 : Q.src_cap - 1, stride, n, lane);
+            const D3 p0{Q.src.x[ql], Q.src.y[ql], Q.src.z[ql]};
+            const int label0 = Q.src.l[ql];
+            const SearchConst sc = search_const(Q.map);
+            const double max_corr = Q.max_corr, th = Q.kernel_th;
+            double acc[kIcpSums];
+#pragma unroll
+            for (int k = 0; k < kIcpSums; ++k) acc[k] = 0.0;
+            accumulate_queries<false>(Q.map, sc, Q.src, n, q0, stride, T_total, p0, label0, max_corr * max_corr, th, th * th, th < 0.0,
+                                      (float)max_corr + 1e-3f, lane, acc);
+            if ((lane & 31) == 0) {
+#pragma unroll
+                for (int k = 0; k < kIcpSums; ++k) red[s][wave][lane >> 5][k] = acc[k];
+            }
+        }
+        if (!any) break;
+        __syncthreads();
+        double *buf = partials2 + (size_t)(it & 1) * kIcpMaxBatch * kIcpSums * kIcpBlocks;
+        if (wave == 0) {
+#pragma unroll 1
+            for (int s = 0; s < S; ++s) {
+                if (s_done[s]) continue;
+                if (lane < kIcpSums) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int w = 0; w < kIcpThreads / 64; ++w) sum += red[s][w][0][lane] + red[s][w][1][lane];
+                    __hip_atomic_store(&buf[((size_t)s * kIcpSums + lane) * kIcpBlocks + blockIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the arrival
+            if (lane == 0)
+                __hip_atomic_fetch_add(&tickets[(blockIdx.x % kIcpTickets) * kIcpTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t share = gridDim.x / kIcpTickets + ((uint32_t)lane < gridDim.x % kIcpTickets ? 1u : 0u);
+            const uint32_t target = (A.ticket_base + (uint32_t)(it + 1)) * share;
+            const bool watcher = lane < kIcpTickets;
+            int abort = 0;
+            for (uint32_t spins = 0;; ++spins) {
+                const uint32_t t = watcher ? __hip_atomic_load(&tickets[lane * kIcpTicketStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                if (__any(watcher && t >= kAbortBit)) { abort = 1; break; }
+                if (__all(!watcher || t >= target)) break;
+                if (spins > kSpinLimit) {
+                    if (watcher) __hip_atomic_fetch_add(&tickets[lane * kIcpTicketStride], kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    abort = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) s_flag = abort;
+        }
+        __syncthreads();
+        if (s_flag) {
+            if (threadIdx.x == 0) bdev->abort = 1;
+            if (blockIdx.x == 0 && threadIdx.x < S)
+                __hip_atomic_store(&A.seq[threadIdx.x].mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        // ---- fold + solve: wave w takes sequences w, w + 4, ...
+#pragma unroll 1
+        for (int s = wave; s < S; s += waves_per_block) {
+            if (s_done[s]) continue;
+            fold_partials_one_wave(buf + (size_t)s * kIcpSums * kIcpBlocks, Ssum[s], lane);
+            wave_lds_sync();
+            wave_solve6(Ssum[s], solve_x[wave], lane);
+            wave_lds_sync();
+            if (lane <= 1) {
+                double x[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) x[i] = solve_x[wave][i];
+                double nn = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) nn += x[i] * x[i];
+                const Rigid est = rigid_exp_small(D3{x[0], x[1], x[2]}, D3{x[3], x[4], x[5]});
+                const Rigid prev = s_T[s][lane];
+                s_T[s][lane] = compose_fast(est, prev);
+                if (lane == 0) {
+                    s_cnt[s][0] += (long long)Ssum[s][16]; s_cnt[s][1] += (long long)Ssum[s][17]; s_cnt[s][2] += (long long)Ssum[s][18];
+                    s_it[s] = it + 1;
+                    if (nn < 1e-8 || it + 1 >= A.max_iter) s_done[s] = 1;  // F/Registration.cpp:169 / :115
+                }
+            }
+            wave_lds_sync();
+        }
+        __syncthreads();
+        ++it;
+    }
+    if (blockIdx.x != 0 || wave != 0) return;
+    {   // a block whose wait ran out during the last iteration while this one passed: counts as given up
+        const uint32_t t = lane < kIcpTickets ? __hip_atomic_load(&tickets[lane * kIcpTicketStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (__any(t >= kAbortBit)) {
+            if (lane == 0) bdev->abort = 1;
+            if (lane < S) __hip_atomic_store(&A.seq[lane].mirror->icp_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
+    if (lane >= S) return;
+    {   // lane s leaves sequence s's result where the single-sequence kernel leaves it
+        const int s = lane;
+        const BatchSeq &Q = A.seq[s];
+        DevState *st = Q.st;
+        HostMirror *mirror = Q.mirror;
+        const int32_t *z = Q.n_ptr - 3;  // the scan's device int32[4] {n_in, n_c, n_d, n_s}
+        st->n_in = z[0]; st->n_c = z[1]; st->n_d = z[2]; st->n_s = z[3];
+        st->guess = Q.guess;
+        st->max_corr = Q.max_corr; st->kernel_th = Q.kernel_th; st->icp_max_iter = A.max_iter;
+        const Rigid T_total = s_T[s][1];
+        st->T_icp = s_T[s][0];
+        st->T_total = T_total;
+        const long long corr = s_cnt[s][0], cand = s_cnt[s][1], probe = s_cnt[s][2];
+        st->icp_corr = corr; st->icp_cand = cand; st->icp_probe = probe;
+        st->icp_iter = s_it[s];
+        st->icp_done = 1;
+        st->icp_abort = 0;
+        mirror->n_in = z[0]; mirror->n_c = z[1]; mirror->n_d = z[2]; mirror->n_s = z[3];
+        mirror->err_flags = st->err_flags;
+        mirror->pose[0] = T_total.qw; mirror->pose[1] = T_total.qx; mirror->pose[2] = T_total.qy; mirror->pose[3] = T_total.qz;
+        mirror->pose[4] = T_total.t.x; mirror->pose[5] = T_total.t.y; mirror->pose[6] = T_total.t.z;
+        mirror->icp_corr = corr; mirror->icp_cand = cand; mirror->icp_probe = probe;
+        mirror->icp_map_live = st->map_live; mirror->icp_map_tomb = st->map_tomb; mirror->icp_map_points = st->map_points;
+        if (A.trace) mirror->t_icp_end = wall_clock64();
+        __hip_atomic_store(&mirror->icp_iter, s_it[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mirror->icp_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ __launch_bounds__(256) void icp_finish_kernel(DevState *st, const double *partials, int nblocks,
                                                          double *__restrict__ out28) {
     __shared__ double S[kIcpSums];
@@ -906,6 +1105,17 @@ bool icp_persistent_fits(int device) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, icp_persistent_kernel<true>, kIcpThreads, 0) != hipSuccess) return false;
     const long resident = (long)std::min(per_cu_a, per_cu_b) * prop.multiProcessorCount;
     return resident >= kIcpBlocks;
+}
+
+void launch_icp_batched(hipStream_t s, const BatchArgs &A, double *partials2, uint32_t *tickets, int32_t *abort_word) {
+    hipLaunchKernelGGL(icp_batched_kernel, dim3(kIcpBlocks), dim3(kIcpThreads), 0, s, A, partials2, tickets, (BatchDev *)abort_word);
+}
+bool icp_batched_fits(int device) {
+    hipDeviceProp_t prop;
+    int per_cu = 0;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_batched_kernel, kIcpThreads, 0) != hipSuccess) return false;
+    return (long)per_cu * prop.multiProcessorCount >= kIcpBlocks;
 }
 
 namespace {

@@ -125,8 +125,28 @@ struct ScanSet {
     int key_n = 0, key_kitti = 0;
 };
 
+// Batch engine (sgs_process_scans_batched_f32_dev): owned by the first context of the first batched call on it
+struct BatchEngine {
+    hipStream_t stream = nullptr;   // the one launch that registers all sequences of a step
+    hipEvent_t ev_icp = nullptr;    // recorded behind that launch: every context's map update waits for it
+    double *partials = nullptr;     // 2 * kIcpMaxBatch * kIcpSums * kIcpBlocks
+    uint32_t *tickets = nullptr;
+    int32_t *abort_word = nullptr;
+    uint32_t ticket_base = 0;
+    bool dirty = true;              // counters / abort word must be zeroed before the next launch
+    bool fits = false;              // all blocks of the batched kernel can be resident at once on this device
+    int64_t launches = 0, fallbacks = 0;
+    // SGS_TRACE=1: host wall-clock of a batched call, summed (ms): fronts acquired | launch + updates enqueued | results in
+    // the mirrors | graphs finished
+    bool trace = false;
+    double tr[4] = {0, 0, 0, 0};
+    long tr_n = 0;
+};
+
 struct sgs_ctx {
     sgs_config cfg;
+    BatchEngine *batch = nullptr;
+    hipEvent_t ev_map = nullptr;     // batched entry point: marks what is queued on `stream` when a batched launch must wait for it
     int device = 0;
     hipStream_t stream = nullptr;   // ICP, map update and every granular entry point
     hipStream_t streamF = nullptr;  // front half of a scan
@@ -139,6 +159,7 @@ struct sgs_ctx {
     HostMirror *mirror = nullptr;    // host-pinned, device-mapped: ICP progress, pose / sizes of the scan, map census
     HostMirror *mirror_dev = nullptr;
     bool async_pending = false;      // a map update of sgs_process_scan is still queued (cfg.async_map_update)
+    bool batch_pending = false;      // ... queued by sgs_process_scans_batched_f32_dev (waits for the batch stream's kernel)
     // Chained registration: when scan k+1 has been prefetched, the call for scan k ends by enqueueing the
     // registration of scan k+1 (its guess and threshold depend only on the poses up to k), so the device goes
     // from the map update of k straight into the Gauss-Newton loop of k+1 without waiting for the host.
@@ -816,13 +837,11 @@ struct ScanSource {
     bool has_ts() const { return d_ts || h_ts; }
 };
 
-int process_scan_dev(sgs_ctx *c, const ScanSource &src, int n, int is_kitti, sgs_scan_result *res) {
-    if (n < 0 || n > c->N) return fail(c, SGS_ECAPACITY, "scan of %d points exceeds max_points=%d", n, c->N);
-    const double t_call0 = now_ms();
-    hipStream_t s = c->stream;
+// front half of the scan: already under way when this scan was prefetched, else enqueued now.  Leaves c->cur on the
+// scan's ScanSet.  Between a hint for scan k+1 and the call for scan k both sets can hold a prefetched scan; take the
+// one that matches, else a free one.
+int acquire_front(sgs_ctx *c, const ScanSource &src, int n, int is_kitti) {
     const sgs_config &cfg = c->cfg;
-    // ---- front half: already under way when this scan was prefetched.  Between a hint for scan k+1 and
-    // the call for scan k both sets can hold a prefetched scan; take the one that matches, else a free one.
     {
         const void *kx = src.key_xyz(), *kl = src.key_label();
         auto matches = [&](const ScanSet &N) {
@@ -857,6 +876,37 @@ int process_scan_dev(sgs_ctx *c, const ScanSource &src, int n, int is_kitti, sgs
             c->gworker.submit([c, ps, slot, n] { graph_enqueue_job(c, *ps, slot, n); });
         }
     }
+    return SGS_OK;
+}
+
+// local-map update of the scan in set S with the pose the registration left in DevState (P/SemGraphSLAM.cpp:113), on
+// the context's stream.  skip (nullable): device word; the four kernels do nothing when it is non-zero.
+int enqueue_map_update(sgs_ctx *c, ScanSet &S, int n, int incoming_upper, const int32_t *skip) {
+    int rr = maybe_rehash(c, incoming_upper);  // sizing by the last census the host has seen plus everything that may have been added since
+    if (rr) return rr;
+    MapView mv = c->map.v;
+    mv.skip = skip;
+    launch_map_add(c->stream, mv, S.ds, S.sizes + 2, n, &c->st->T_total, c->map_slot_of, c->map_next, c->world, c->st);
+    launch_map_sweep(c->stream, mv, &c->st->T_total, nullptr, c->cfg.max_range, 1, c->map_blockstat, c->st, c->mirror_dev);
+    SGS_HIP(c, hipEventRecord(S.ev_free, c->stream));
+    S.free_recorded = true;
+    return SGS_OK;
+}
+
+int process_scan_dev(sgs_ctx *c, const ScanSource &src, int n, int is_kitti, sgs_scan_result *res) {
+    if (n < 0 || n > c->N) return fail(c, SGS_ECAPACITY, "scan of %d points exceeds max_points=%d", n, c->N);
+    const double t_call0 = now_ms();
+    hipStream_t s = c->stream;
+    const sgs_config &cfg = c->cfg;
+    if (c->batch_pending) {  // the context was last driven through the batched entry point: its update may still be queued
+        SGS_HIP(c, hipStreamSynchronize(c->stream));
+        c->batch_pending = false;
+    }
+    {
+        const int rf = acquire_front(c, src, n, is_kitti);
+        if (rf) return rf;
+    }
+    ScanSet &S = c->S();
     struct JobGuard {  // never leave the helper running on this set past this call
         ScanSet *s;
         ~JobGuard() { wait_set_job(*s); }
@@ -890,16 +940,7 @@ int process_scan_dev(sgs_ctx *c, const ScanSource &src, int n, int is_kitti, sgs
     const bool track = cfg.relocalization_enable != 0 && cfg.enable_graph != 0;  // instance tracking + relocalization: strictly serial
     const bool ahead = cfg.async_map_update != 0 && !c->profiling && c->shard_world == 1 && c->icp_persistent && c->map_live_host != 0 && !track;
     auto enqueue_map_update = [&](bool guarded) -> int {
-        // sizing by the last census the host has seen plus everything that may have been added since
-        int rr = maybe_rehash(c, guarded ? n + c->last_n[3] : n);
-        if (rr) return rr;
-        MapView mv = c->map.v;
-        mv.skip = guarded ? &c->st->icp_abort : nullptr;
-        launch_map_add(s, mv, S.ds, S.sizes + 2, n, &c->st->T_total, c->map_slot_of, c->map_next, c->world, c->st);
-        launch_map_sweep(s, mv, &c->st->T_total, nullptr, cfg.max_range, 1, c->map_blockstat, c->st, c->mirror_dev);
-        SGS_HIP(c, hipEventRecord(S.ev_free, s));
-        S.free_recorded = true;
-        return SGS_OK;
+        return ::enqueue_map_update(c, S, n, guarded ? n + c->last_n[3] : n, guarded ? &c->st->icp_abort : nullptr);
     };
     if (ahead) {
         if (!chained) {
@@ -1052,6 +1093,212 @@ int process_scan_dev(sgs_ctx *c, const ScanSource &src, int n, int is_kitti, sgs
     return SGS_OK;
 }
 
+int batch_engine_get(sgs_ctx *lead, BatchEngine **out) {
+    if (!lead->batch) {
+        BatchEngine *e = new BatchEngine();
+        lead->batch = e;  // freed by sgs_destroy whatever happens below
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail(lead, SGS_EHIP, "batch stream");
+        if (hipEventCreateWithFlags(&e->ev_icp, hipEventDisableTiming) != hipSuccess) return fail(lead, SGS_EHIP, "batch event");
+        if (hipMalloc((void **)&e->partials, sizeof(double) * 2 * kIcpMaxBatch * kIcpSums * kIcpBlocks) != hipSuccess ||
+            hipMalloc((void **)&e->tickets, sizeof(uint32_t) * kIcpTicketWords) != hipSuccess ||
+            hipMalloc((void **)&e->abort_word, 256) != hipSuccess)
+            return fail(lead, SGS_ENOMEM, "batch engine allocation failed");
+        e->fits = icp_batched_fits(lead->device);
+        e->trace = lead->trace;
+    }
+    *out = lead->batch;
+    return SGS_OK;
+}
+
+// wait until a registration's result is in the context's host mirror; *done_out = 1 result there, 2 the launch gave up
+int wait_mirror_done(sgs_ctx *c, hipStream_t launch_stream, int *done_out) {
+    volatile int32_t *mb = &c->mirror->icp_iter;
+    long spins = 0;
+    int done;
+    while (!(done = __atomic_load_n(&mb[1], __ATOMIC_ACQUIRE))) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFF) == 0) {
+            const hipError_t q = hipStreamQuery(launch_stream);
+            if (q == hipSuccess) {
+                if (!(done = __atomic_load_n(&mb[1], __ATOMIC_ACQUIRE))) return fail(c, SGS_EHIP, "batched ICP kernel ended without reporting");
+                break;
+            } else if (q != hipErrorNotReady) {
+                return fail(c, SGS_EHIP, "batched ICP loop: %s", hipGetErrorString(q));
+            }
+        }
+    }
+    *done_out = done;
+    return SGS_OK;
+}
+
+// One step of S independent scan sequences (one context each, all on one device): what S calls of
+// sgs_process_scan_f32_dev with cfg.async_map_update = 1 do, with ONE registration launch for all of them.
+int process_batch(sgs_ctx *const *ctxs, int S, const ScanSource *srcs, const int *n, int is_kitti, sgs_scan_result *results) {
+    sgs_ctx *lead = ctxs[0];
+    BatchEngine *E = nullptr;
+    int r;
+    if ((r = batch_engine_get(lead, &E))) return r;
+    const double t_call0 = now_ms();
+    // ---- front halves (normally prefetched), motion prediction and thresholds (P/SemGraphSLAM.cpp:57-63)
+    Rigid guess[kIcpMaxBatch];
+    double sigma[kIcpMaxBatch];
+    bool skip[kIcpMaxBatch];
+    struct Guards {  // never leave a helper thread running on a set past this call
+        sgs_ctx *const *c;
+        int S;
+        ~Guards() { for (int s = 0; s < S; ++s) wait_set_job(c[s]->S()); }
+    } guards{ctxs, S};
+    for (int s = 0; s < S; ++s) {
+        sgs_ctx *c = ctxs[s];
+        if (n[s] < 0 || n[s] > c->N) return fail(lead, SGS_ECAPACITY, "sequence %d: scan of %d points exceeds max_points=%d", s, n[s], c->N);
+        if ((r = cancel_chained_icp(c))) return fail(lead, r, "sequence %d: %s", s, c->err.c_str());
+        if ((r = acquire_front(c, srcs[s], n[s], is_kitti))) return fail(lead, r, "sequence %d: %s", s, c->err.c_str());
+        if (c->next_params_valid) {
+            sigma[s] = c->next_sigma; guess[s] = c->next_guess;
+            c->next_params_valid = false;
+        } else {
+            next_scan_params(c, &guess[s], &sigma[s]);
+        }
+        skip[s] = c->map_live_host == 0;  // F/Registration.cpp:152: empty map -> the initial guess, no iteration
+        // the table may have to grow before the update of this scan: now, while nothing of this step reads it
+        if ((r = maybe_rehash(c, n[s] + c->last_n[3]))) return fail(lead, r, "sequence %d: %s", s, c->err.c_str());
+    }
+    const double t_front = now_ms();
+    // ---- one launch registers all sequences (P/SemGraphSLAM.cpp:72-76 each)
+    const bool use_kernel = E->fits;
+    bool gave_up = !use_kernel;
+    if (use_kernel) {
+        BatchArgs A;
+        memset((void *)&A, 0, sizeof(A));
+        A.S = S; A.max_iter = kIcpMaxIter; A.trace = 0;
+        for (int s = 0; s < S; ++s) {
+            sgs_ctx *c = ctxs[s];
+            ScanSet &Z = c->S();
+            BatchSeq &q = A.seq[s];
+            q.map = c->map.v; q.map.skip = nullptr;
+            q.src = Z.src; q.n_ptr = Z.sizes + 3; q.src_cap = c->N; q.skip = skip[s] ? 1 : 0;
+            q.st = c->st; q.mirror = c->mirror_dev;
+            q.guess = guess[s]; q.max_corr = 3.0 * sigma[s]; q.kernel_th = sigma[s] / 3.0;
+            SGS_HIP(lead, hipStreamWaitEvent(E->stream, Z.ev_front, 0));
+            // everything queued on the context's own stream so far - its previous map update, batched or not - comes first
+            SGS_HIP(lead, hipEventRecord(c->ev_map, c->stream));
+            SGS_HIP(lead, hipStreamWaitEvent(E->stream, c->ev_map, 0));
+            c->mirror->icp_iter = 0;
+            c->mirror->icp_done = 0;
+        }
+        if (E->dirty || E->ticket_base > (1u << 26)) {
+            SGS_HIP(lead, hipMemsetAsync(E->tickets, 0, sizeof(uint32_t) * kIcpTicketWords, E->stream));
+            SGS_HIP(lead, hipMemsetAsync(E->abort_word, 0, sizeof(int32_t), E->stream));
+            E->dirty = false;
+            E->ticket_base = 0;
+        }
+        A.ticket_base = E->ticket_base;
+        __sync_synchronize();
+        launch_icp_batched(E->stream, A, E->partials, E->tickets, E->abort_word);
+        SGS_HIP(lead, hipEventRecord(E->ev_icp, E->stream));
+        E->launches++;
+        // ---- every context's map update right behind it, each on its own stream (P/SemGraphSLAM.cpp:113)
+        for (int s = 0; s < S; ++s) {
+            sgs_ctx *c = ctxs[s];
+            SGS_HIP(lead, hipStreamWaitEvent(c->stream, E->ev_icp, 0));
+            if ((r = enqueue_map_update(c, c->S(), n[s], 0, E->abort_word))) return fail(lead, r, "sequence %d: %s", s, c->err.c_str());
+        }
+        if (E->trace) E->tr[1] += now_ms() - t_front;
+        int iters_run = 0;
+        for (int s = 0; s < S; ++s) {
+            int done = 0;
+            if ((r = wait_mirror_done(ctxs[s], E->stream, &done))) return fail(lead, r, "sequence %d: %s", s, ctxs[s]->err.c_str());
+            if (done == 2) gave_up = true;
+            else iters_run = std::max(iters_run, (int)ctxs[s]->mirror->icp_iter);
+        }
+        if (!gave_up) E->ticket_base += (uint32_t)iters_run;
+    }
+    int iters[kIcpMaxBatch];
+    if (gave_up) {  // every queued update skipped itself: register and update sequence by sequence, the slow way
+        if (use_kernel) {
+            SGS_HIP(lead, hipStreamSynchronize(E->stream));
+            E->dirty = true;
+            E->fallbacks++;
+        }
+        for (int s = 0; s < S; ++s) {
+            sgs_ctx *c = ctxs[s];
+            ScanSet &Z = c->S();
+            SGS_HIP(lead, hipStreamWaitEvent(c->stream, Z.ev_front, 0));
+            iters[s] = 0;
+            if ((r = run_icp(c, Z.src, Z.sizes + 3, Z.sizes, guess[s], 3.0 * sigma[s], sigma[s] / 3.0, &iters[s]))) return fail(lead, r, "sequence %d: %s", s, c->err.c_str());
+            if ((r = enqueue_map_update(c, Z, n[s], n[s], nullptr))) return fail(lead, r, "sequence %d: %s", s, c->err.c_str());
+            c->stats.icp_fallbacks++;
+        }
+    }
+    const double t_done = now_ms();
+    double t_graph = 0;
+    // ---- results (P/SemGraphSLAM.cpp:79,110,119), per sequence
+    for (int s = 0; s < S; ++s) {
+        sgs_ctx *c = ctxs[s];
+        ScanSet &Z = c->S();
+        DevState hs;
+        if (gave_up || skip[s]) {  // nothing ran ahead of the host: read the state behind the update (as the serial path does)
+            if ((r = sync_state(c))) return fail(lead, r, "sequence %d: %s", s, c->err.c_str());
+            hs = *c->st_host;
+            if (!gave_up) iters[s] = 0;
+        } else {
+            const HostMirror &mi = *c->mirror;
+            iters[s] = mi.icp_iter;
+            c->map_live_host = mi.icp_map_live; c->map_tomb_host = mi.icp_map_tomb; c->map_points_host = mi.icp_map_points;
+            hs.n_in = mi.n_in; hs.n_c = mi.n_c; hs.n_d = mi.n_d; hs.n_s = mi.n_s;
+            hs.err_flags = mi.err_flags | mi.map_err_flags;
+            hs.T_total = Rigid{mi.pose[0], mi.pose[1], mi.pose[2], mi.pose[3], D3{mi.pose[4], mi.pose[5], mi.pose[6]}};
+            hs.icp_corr = mi.icp_corr; hs.icp_cand = mi.icp_cand; hs.icp_probe = mi.icp_probe;
+            hs.map_live = mi.icp_map_live;  // voxels of the map this scan was registered against
+            c->async_pending = true;
+            c->batch_pending = true;
+        }
+        c->prev_iters = iters[s];
+        if ((r = check_err_flags(c, hs.err_flags))) return fail(lead, r, "sequence %d: %s", s, c->err.c_str());
+        const Rigid new_pose = hs.T_total;
+        c->model_deviation = compose(invert(guess[s]), new_pose);
+        c->poses.push_back(new_pose);
+        int n_boxes = 0;
+        if (c->cfg.enable_graph) {
+            const double tg0 = now_ms();
+            wait_set_job(Z);
+            t_graph += now_ms() - tg0;
+            if (Z.graph_rc) return fail(lead, Z.graph_rc, "sequence %d: %s", s, Z.gerr.c_str());
+            n_boxes = Z.n_boxes;
+        }
+        c->last_n[0] = n[s]; c->last_n[1] = hs.n_in; c->last_n[2] = hs.n_c; c->last_n[3] = hs.n_d; c->last_n[4] = hs.n_s;
+        c->stats.scans++;
+        c->stats.icp_queries_total += (int64_t)hs.n_s * iters[s];
+        c->stats.icp_candidates_total += hs.icp_cand;
+        c->stats.icp_probes_total += hs.icp_probe;
+        if (results) {
+            sgs_scan_result &o = results[s];
+            const uint32_t sz = o.size ? std::min<uint32_t>(o.size, sizeof(sgs_scan_result)) : sizeof(sgs_scan_result);
+            sgs_scan_result t;
+            memset(&t, 0, sizeof(t));
+            t.size = sz;
+            t.icp_iterations = iters[s];
+            rigid_to_pose7(new_pose, t.pose);
+            rigid_to_pose7(guess[s], t.initial_guess);
+            t.sigma = sigma[s];
+            t.n_raw = n[s]; t.n_in = hs.n_in; t.n_cluster = hs.n_c; t.n_ds = hs.n_d; t.n_src = hs.n_s;
+            t.n_boxes = n_boxes;
+            t.map_voxels = hs.map_live;
+            t.icp_correspondences = hs.icp_corr;
+            t.icp_candidates = hs.icp_cand;
+            memcpy(&o, &t, sz);
+        }
+    }
+    lead->stats.stage_ms[6] += now_ms() - t_call0;
+    if (E->trace) {
+        E->tr[0] += t_front - t_call0;
+        E->tr[2] += t_done - t_front;
+        E->tr[3] += t_graph;
+        E->tr_n++;
+    }
+    return SGS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1184,6 +1431,9 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     }
     if ((r = dev_alloc(c, &c->out28, 32))) return bail(r);
     if ((r = dev_alloc(c, &c->tickets, (size_t)kIcpTicketWords))) return bail(r);
+    // a host-initialised launch counts on from whatever the counters hold: they must start at zero even when no
+    // icp_init kernel ever runs on this context (a context driven through the batched entry point only)
+    if (hipMemsetAsync(c->tickets, 0, sizeof(uint32_t) * kIcpTicketWords, c->stream) != hipSuccess) return bail(SGS_EHIP);
     if ((r = dev_alloc(c, &c->corr_tgt, N * 4))) return bail(r);
     if ((r = dev_alloc(c, &c->corr_found, N))) return bail(r);
     if ((r = dev_alloc(c, &c->st, 1))) return bail(r);
@@ -1200,6 +1450,7 @@ int sgs_create(const sgs_config *cfg_in, int device, sgs_ctx **out) {
     for (int k = 0; k < 8; ++k)
         if (hipEventCreate(&c->stage_ev[k]) != hipSuccess) return bail(SGS_EHIP);
     c->stage_ev_ok = true;
+    if (hipEventCreateWithFlags(&c->ev_map, hipEventDisableTiming) != hipSuccess) return bail(SGS_EHIP);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(SGS_EHIP);
     *out = c;
     return SGS_OK;
@@ -1224,6 +1475,20 @@ void sgs_destroy(sgs_ctx *c) {
         if (S.ev_front) hipEventDestroy(S.ev_front);
         if (S.ev_free) hipEventDestroy(S.ev_free);
     }
+    if (c->batch) {
+        BatchEngine *e = c->batch;
+        if (e->trace && e->tr_n)
+            fprintf(stderr, "[sgs trace] batched: %ld calls, host ms per call: fronts acquired %.4f | launch + updates enqueued %.4f | launch -> results in the mirrors %.4f | waiting for graphs %.4f\n",
+                    e->tr_n, e->tr[0] / e->tr_n, e->tr[1] / e->tr_n, e->tr[2] / e->tr_n, e->tr[3] / e->tr_n);
+        if (e->stream) { hipStreamSynchronize(e->stream); hipStreamDestroy(e->stream); }
+        if (e->ev_icp) hipEventDestroy(e->ev_icp);
+        if (e->partials) hipFree(e->partials);
+        if (e->tickets) hipFree(e->tickets);
+        if (e->abort_word) hipFree(e->abort_word);
+        delete e;
+        c->batch = nullptr;
+    }
+    if (c->ev_map) hipEventDestroy(c->ev_map);
     if (c->streamF) hipStreamDestroy(c->streamF);
     if (c->ev_g0) hipEventDestroy(c->ev_g0);
     if (c->ev_g1) hipEventDestroy(c->ev_g1);
@@ -1916,6 +2181,27 @@ int sgs_prefetch_scan_f32(sgs_ctx *c, const float *xyzi, const int32_t *label, i
     ScanSource src;
     src.h_f32 = xyzi; src.h_label = label;
     return prefetch_common(c, src, n, is_kitti);
+}
+int sgs_process_scans_batched_f32_dev(sgs_ctx *const *ctxs, int S, const float *const *xyzi_dev, const int32_t *const *label_dev,
+                                      const int *n, int is_kitti, sgs_scan_result *results) {
+    if (!ctxs || S < 1 || !ctxs[0]) return SGS_EINVAL;
+    sgs_ctx *lead = ctxs[0];
+    if (S > kIcpMaxBatch) return fail(lead, SGS_ECAPACITY, "at most %d sequences per batched call", kIcpMaxBatch);
+    if (!xyzi_dev || !label_dev || !n) return fail(lead, SGS_EINVAL, "null argument");
+    ScanSource srcs[kIcpMaxBatch];
+    for (int s = 0; s < S; ++s) {
+        sgs_ctx *c = ctxs[s];
+        if (!c) return fail(lead, SGS_EINVAL, "sequence %d: null context", s);
+        for (int t = 0; t < s; ++t)
+            if (ctxs[t] == c) return fail(lead, SGS_EINVAL, "sequence %d: the same context twice", s);
+        if (c->device != lead->device) return fail(lead, SGS_EINVAL, "sequence %d: all contexts of a batch must be on one device", s);
+        if (c->shard_world > 1 || c->profiling || (c->cfg.relocalization_enable && c->cfg.enable_graph) || c->cfg.deskew)
+            return fail(lead, SGS_EINVAL, "sequence %d: sharded, profiled, deskewing or relocalizing contexts take the single-sequence entry points", s);
+        if (n[s] && (!xyzi_dev[s] || !label_dev[s])) return fail(lead, SGS_EINVAL, "sequence %d: null scan", s);
+        srcs[s].d_f32 = xyzi_dev[s]; srcs[s].d_label = label_dev[s];
+    }
+    if (hipSetDevice(lead->device) != hipSuccess) return fail(lead, SGS_EHIP, "hipSetDevice failed");
+    return process_batch(ctxs, S, srcs, n, is_kitti, results);
 }
 int sgs_get_cloud(sgs_ctx *c, int which, double *xyz, int32_t *label, int cap, int *n) {
     ENTER(c);

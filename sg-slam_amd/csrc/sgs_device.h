@@ -168,6 +168,29 @@ void launch_icp_iteration(hipStream_t s, MapView m, CloudView src, int src_cap /
 // launch_icp_iteration)
 void launch_icp_persistent(hipStream_t s, MapView m, CloudView src, int src_cap, const int32_t *n_ptr, DevState *st,
                            double *partials2, uint32_t *tickets, HostMirror *mirror);
+// ---- several sequences' Gauss-Newton loops in one launch (sgs_process_scans_batched_f32_dev) ----
+constexpr int kIcpMaxBatch = 8;
+struct BatchSeq {
+    MapView map;
+    CloudView src;          // the scan's source cloud (a ScanSet's src)
+    const int32_t *n_ptr;   // word 3 of that set's device int32[4]
+    int32_t src_cap;        // elements allocated per cloud array
+    int32_t skip;           // 1: no registration (empty map): the pose is the guess, 0 iterations
+    DevState *st;
+    HostMirror *mirror;     // host-mapped: where the result goes
+    Rigid guess;
+    double max_corr, kernel_th;
+};
+struct BatchArgs {
+    BatchSeq seq[kIcpMaxBatch];
+    int32_t S, max_iter;
+    uint32_t ticket_base;
+    int32_t trace;
+};
+// partials2: 2 * kIcpMaxBatch * kIcpSums * kIcpBlocks doubles; tickets: kIcpTicketWords, zero before the first launch;
+// abort_word: device int32, set when the launch gave up (then every mirror's icp_done is 2)
+void launch_icp_batched(hipStream_t s, const BatchArgs &A, double *partials2, uint32_t *tickets, int32_t *abort_word);
+bool icp_batched_fits(int device);
 bool icp_persistent_fits(int device);  // all kIcpBlocks blocks of the one-launch loop resident at once on this device?
 void launch_icp_set_pose(hipStream_t s, DevState *st, const Rigid &T_icp, const Rigid &T_total, int iter, long long corr);
 void launch_correspondences(hipStream_t s, MapView m, CloudView src, int n, double max_dist, double *tgt_xyzl,

@@ -1356,3 +1356,87 @@ def test_pipeline_host_prefetch_matches_serial():
     assert np.array_equal(ka, kb) and np.array_equal(ca, cb) and np.array_equal(pa, pb)
     a.close()
     b.close()
+
+
+# The batched entry point is EXPERIMENTAL: these tests passed on MI355X with the runtime's default
+# GPU_MAX_HW_QUEUES=4 (profiles/r2_batched_tests.log), but a throughput probe of it under GPU_MAX_HW_QUEUES=8 ended in
+# an illegal memory access whose cause could not be found before the round's GPU access ended.  Until it is found the
+# tests only run on request, so that an unexplained fault cannot take the rest of the GPU suite down with it.
+_BATCHED = pytest.mark.skipif(__import__("os").environ.get("SGS_TEST_BATCHED") != "1",
+                              reason="experimental entry point: set SGS_TEST_BATCHED=1 to run")
+
+
+@_BATCHED
+@pytest.mark.parametrize("S", [1, 2, 4, 5, 8])
+def test_batched_sequences_match_single_sequence_calls_bit_for_bit(S):
+    """sgs_process_scans_batched_f32_dev: S sequences (different drives: sequence s starts at frame 7 s) stepped in one
+    registration launch, against the same sequences through sgs_process_scan_f32_dev one context at a time: poses,
+    iteration counts, sizes, boxes, clouds and final maps must be identical bits; hints right, wrong and missing."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    steps = 12
+    shape = "small"
+
+    def dev(a):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), a.nbytes) == 0 and hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+        return p
+    frames = sorted({7 * s + k for s in range(S) for k in range(steps)})
+    host = {f: synth.scan(f, shape) for f in frames}
+    d_x = {f: dev(np.ascontiguousarray(host[f][0], dtype=np.float32)) for f in frames}
+    d_l = {f: dev(np.ascontiguousarray(host[f][2], dtype=np.int32)) for f in frames}
+    n = len(host[frames[0]][2])
+    batch_ctxs = [make_ctx(async_map_update=1) for _ in range(S)]
+    single = [make_ctx() for _ in range(S)]
+    batch = api.Batch(batch_ctxs)
+    for k in range(steps):
+        cur = [7 * s + k for s in range(S)]
+        if k + 1 < steps and k % 5 != 3:  # sometimes no hints at all
+            for s in range(S):
+                nxt = cur[s] + 1 if (k + s) % 4 != 2 else cur[s]  # sometimes a wrong hint
+                batch_ctxs[s].prefetch_scan_dev(d_x[nxt].value, d_l[nxt].value, n, "")
+        res = batch.process([d_x[f].value for f in cur], [d_l[f].value for f in cur], [n] * S)
+        for s in range(S):
+            rb = single[s].process_scan_dev(d_x[cur[s]].value, d_l[cur[s]].value, n)
+            ra = res[s]
+            assert list(ra.pose) == list(rb.pose) and ra.icp_iterations == rb.icp_iterations, (k, s)
+            assert (ra.n_in, ra.n_cluster, ra.n_ds, ra.n_src, ra.n_boxes) == (rb.n_in, rb.n_cluster, rb.n_ds, rb.n_src, rb.n_boxes)
+            assert ra.icp_correspondences == rb.icp_correspondences and ra.icp_candidates == rb.icp_candidates
+            assert ra.sigma == rb.sigma and list(ra.initial_guess) == list(rb.initial_guess)
+        if k % 4 == 1:  # accessors in between settle the queued updates and must see this step's scan
+            for s in range(S):
+                assert np.array_equal(batch_ctxs[s].boxes(), single[s].boxes())
+                assert np.array_equal(batch_ctxs[s].cloud(3)[0], single[s].cloud(3)[0])
+    for s in range(S):
+        ka, ca, pa = batch_ctxs[s].map_dump()
+        kb, cb, pb = single[s].map_dump()
+        assert np.array_equal(ka, kb) and np.array_equal(ca, cb) and np.array_equal(pa, pb)
+        assert np.array_equal(batch_ctxs[s].poses(), single[s].poses())
+        assert batch_ctxs[s].stats().icp_fallbacks == 0
+    # a context of the batch can go on alone through the single-sequence entry point
+    f = 7 * 0 + steps
+    xyzi, _, lab = synth.scan(f, shape)
+    ra, rb = batch_ctxs[0].process_scan_f32(xyzi, lab, None, ""), single[0].process_scan_f32(xyzi, lab, None, "")
+    assert np.array_equal(ra["pose"], rb["pose"]) and ra["iterations"] == rb["iterations"]
+    for c in batch_ctxs + single:
+        c.close()
+    for p in list(d_x.values()) + list(d_l.values()):
+        hip.hipFree(p)
+
+
+def test_batched_entry_point_rejects_what_it_cannot_serve():
+    a, b = make_ctx(), make_ctx(deskew=1)
+    L = api.lib()
+    h2 = (api.c_vp * 2)(a.h, a.h)
+    z = (api.c_vp * 2)()
+    nn = (api.c_int * 2)(0, 0)
+    assert L.sgs_process_scans_batched_f32_dev(h2, 2, z, z, nn, 0, None) == api.SGS_EINVAL and b"twice" in L.sgs_last_error(a.h)
+    h2 = (api.c_vp * 2)(a.h, b.h)
+    assert L.sgs_process_scans_batched_f32_dev(h2, 2, z, z, nn, 0, None) == api.SGS_EINVAL and b"deskew" in L.sgs_last_error(a.h)
+    h9 = (api.c_vp * 9)(*([a.h] * 9))
+    assert L.sgs_process_scans_batched_f32_dev(h9, 9, z, z, nn, 0, None) == api.SGS_ECAPACITY
+    a.close()
+    b.close()
