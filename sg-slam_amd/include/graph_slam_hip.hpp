@@ -2,7 +2,10 @@
 // the C ABI in include/sgs.h.  A maintainer of nubot-nudt/SG-SLAM swaps these declarations in for
 //   semgraph_slam/frontend/Preprocessing.hpp:38-52, Deskew.hpp:33-36, VoxelHashMap.hpp:37-83,
 //   Registration.hpp:62-66, SemanticCluster.hpp:81-87, SemGraph.hpp:18
-// and links libsgs_hip.so; SemGraphSLAM::mainProcess (pipeline/SemGraphSLAM.cpp:16-121) compiles unchanged.
+// and links libsgs_hip.so; SemGraphSLAM::mainProcess (pipeline/SemGraphSLAM.cpp:16-121) compiles unchanged.  Graph,
+// Bbox, InsNode (core/Coreutils.h:48-87) and AdaptiveThreshold (frontend/Threshold.hpp:30-53) are declared member for
+// member, so the reference's other users of a Graph (loopclosure/LoopClosure.cpp:328, frontend/GraphMap.cpp:202,
+// pipeline/SemGraphMapping.cpp:54) see the members they touch.
 //
 // With Eigen + Sophus available the facade uses them (SGS_FACADE_WITH_EIGEN, auto-detected).  Without
 // (this build container has neither) it is instantiated on the small POD types below so that it is
@@ -13,6 +16,7 @@
 // stderr and returns empty/identity results, it never throws.
 #pragma once
 #include <array>
+#include <cmath>
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -82,17 +86,97 @@ struct Bbox {
     double score = 0.0;
     int points_num = 0;
 };
-// core/Coreutils.h:59-78 (dense matrices flattened row-major instead of Eigen::MatrixXd)
+#if SGS_FACADE_WITH_EIGEN
+using MatrixXd = Eigen::MatrixXd;
+#else
+// The subset of Eigen::MatrixXd the reference's users of Graph touch (core/Coreutils.h:71-72; SemGraph.cpp:84-86,105;
+// loopclosure/LoopClosure.cpp:328-331: `auto e = g.edge_matrix.row(i); e.size(); e[m]`), column-major like Eigen.
+class MatrixXd {
+public:
+    MatrixXd() = default;
+    MatrixXd(long rows, long cols) : r_(rows), c_(cols), v_((size_t)(rows * cols), 0.0) {}
+    static MatrixXd Zero(long rows, long cols) { return MatrixXd(rows, cols); }
+    long rows() const { return r_; }
+    long cols() const { return c_; }
+    long size() const { return r_ * c_; }
+    double &operator()(long i, long j) { return v_[(size_t)(j * r_ + i)]; }
+    double operator()(long i, long j) const { return v_[(size_t)(j * r_ + i)]; }
+    const double *data() const { return v_.data(); }
+    double *data() { return v_.data(); }
+    void resize(long rows, long cols) { r_ = rows; c_ = cols; v_.assign((size_t)(rows * cols), 0.0); }
+    void setZero() { v_.assign(v_.size(), 0.0); }
+    struct ConstRow {
+        const MatrixXd *m;
+        long i;
+        long size() const { return m->cols(); }
+        double operator[](long j) const { return (*m)(i, j); }
+        double operator()(long j) const { return (*m)(i, j); }
+    };
+    ConstRow row(long i) const { return ConstRow{this, i}; }
+private:
+    long r_ = 0, c_ = 0;
+    std::vector<double> v_;
+};
+#endif
+// core/Coreutils.h:59-78, member for member
 struct Graph {
-    std::vector<int> node_labels, points_num;
-    std::vector<Vec3> node_centers, node_dimensions;
+    std::vector<int> node_labels;
+    std::vector<int> points_num;
+    std::vector<Vec3> node_centers;
     std::vector<std::vector<Vec3>> node_sub_triangles;
+    std::vector<Vec3> node_dimensions;
     std::vector<std::vector<float>> node_desc;
     std::vector<std::pair<int, int>> edges;
-    std::vector<double> edge_value, edge_weights;
-    std::vector<double> edge_matrix;  // N*N
-    V3d_i back_points, front_points;
-    int vehicle_num = 0, trunk_num = 0, pole_like_num = 0;
+    std::vector<int> new_instance;   // filled by GraphMap::Update (frontend/GraphMap.cpp:202)
+    std::vector<double> edge_value;
+    std::vector<double> edge_weights;
+    MatrixXd graph_matrix;           // never assigned by the reference's BuildGraph either (SemGraph.cpp:14-108)
+    MatrixXd edge_matrix;            // N x N centre distances below edge_dis_th, 0 elsewhere (SemGraph.cpp:41,105)
+    V3d_i back_points;
+    V3d_i front_points;
+    int vehicle_num = 0;
+    int trunk_num = 0;
+    int pole_like_num = 0;
+};
+// core/Coreutils.h:81-87
+struct InsNode {
+    int label;
+    int id;
+    Vec3 pose;
+    Vec3 dimension;
+    int points_num;
+};
+
+// frontend/Threshold.hpp:30-53 + Threshold.cpp:29-50: scalar host code, restated on the facade's Pose (it needs no device).
+struct AdaptiveThreshold {
+    explicit AdaptiveThreshold(double initial_threshold, double min_motion_th, double max_range)
+        : initial_threshold_(initial_threshold), min_motion_th_(min_motion_th), max_range_(max_range) {}
+    /// Update the current belief of the deviation from the prediction model
+    inline void UpdateModelDeviation(const Pose &current_deviation) { model_deviation_ = current_deviation; }
+    /// Returns the KISS-ICP adaptive threshold used in registration
+    double ComputeThreshold() {
+        double p[7];
+        pose_to7(model_deviation_, p);
+        // Eigen::AngleAxisd(R).angle() = 2 atan2(|q.vec|, |q.w|); model error = |t| + 2 max_range sin(theta / 2)
+        const double theta = 2.0 * std::atan2(std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]), std::fabs(p[3]));
+        const double delta_rot = 2.0 * max_range_ * std::sin(theta / 2.0);
+        const double delta_trans = std::sqrt(p[4] * p[4] + (p[5] * p[5] + p[6] * p[6]));
+        const double model_error = delta_trans + delta_rot;
+        if (model_error > min_motion_th_) {
+            model_error_sse2_ += model_error * model_error;
+            num_samples_++;
+        }
+        if (num_samples_ < 1) return initial_threshold_;
+        return std::sqrt(model_error_sse2_ / num_samples_);
+    }
+    // configurable parameters
+    double initial_threshold_;
+    double min_motion_th_;
+    double max_range_;
+    // Local cache for computation
+    double model_error_sse2_ = 0;
+    int num_samples_ = 0;
+    Pose model_deviation_ = Pose();
 };
 
 // One device context per thread of use (the reference's VoxelHashMap is not thread safe either).
@@ -298,16 +382,19 @@ inline Graph BuildGraph(const std::vector<Bbox> &cluster_boxes, double edge_dis_
     if (!c || nb == 0) return g;
     const int D = 3 * subinterval + graph_node_dimension;
     std::vector<float> desc((size_t)nb * D);
-    g.edge_matrix.assign((size_t)nb * nb, 0.0);
+    std::vector<double> em((size_t)nb * nb, 0.0);  // row-major from the ABI
     const int ecap = nb * nb, tcap = nb * nb * nb;
     std::vector<int32_t> edges(2 * (size_t)ecap), tri_counts((size_t)nb);
     std::vector<double> ev((size_t)ecap), ew((size_t)ecap), tri(3 * (size_t)tcap);
     int ne = 0, nt = 0;
     int32_t cc[3] = {0, 0, 0};
     if (!ok(c, sgs_build_graph(c, boxes.data(), nb, edge_dis_th, subinterval, graph_node_dimension, subgraph_edge_th, desc.data(),
-                               g.edge_matrix.data(), nullptr, edges.data(), ev.data(), ew.data(), ecap, &ne, tri_counts.data(),
+                               em.data(), nullptr, edges.data(), ev.data(), ew.data(), ecap, &ne, tri_counts.data(),
                                tri.data(), tcap, &nt, cc), "BuildGraph"))
         return g;
+    g.edge_matrix = MatrixXd::Zero(nb, nb);
+    for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < nb; ++j) g.edge_matrix(i, j) = em[(size_t)i * nb + j];
     g.vehicle_num = cc[0]; g.trunk_num = cc[1]; g.pole_like_num = cc[2];
     for (int i = 0; i < nb; ++i) g.node_desc.emplace_back(desc.begin() + (size_t)i * D, desc.begin() + (size_t)(i + 1) * D);
     for (int i = 0; i < ne; ++i) {
@@ -388,7 +475,14 @@ private:
 // ---- frontend/GraphMap.hpp:23-71 (the instance map lives in the context; Graph::new_instance is the second result)
 using VTbii = std::vector<std::tuple<bool, int, int>>;
 struct GraphMap {
-    // FindInsMatch + Update in one step, as mainProcess uses them (SemGraphSLAM.cpp:54,116)
+    // FindInsMatch + Update in one step, as mainProcess uses them (SemGraphSLAM.cpp:54,116); like GraphMap::Update
+    // (GraphMap.cpp:202) the overload that takes the graph by non-const reference records the new instances in it
+    VTbii Track(Graph &graph, const Pose &pose) {
+        std::vector<int> fresh;
+        VTbii out = Track(static_cast<const Graph &>(graph), pose, &fresh);
+        for (int id : fresh) graph.new_instance.emplace_back(id);
+        return out;
+    }
     VTbii Track(const Graph &graph, const Pose &pose, std::vector<int> *new_instance = nullptr) {
         VTbii out;
         sgs_ctx *c = HipContext::instance().get();
