@@ -75,7 +75,7 @@ int main() {
         if (g.edge_matrix.rows() != N || g.edge_matrix.cols() != N) { std::printf("facade FAILED: edge_matrix shape\n"); return 5; }
         for (size_t e = 0; e < g.edges.size(); ++e)
             if (g.edge_matrix(g.edges[e].first, g.edges[e].second) != g.edge_value[e] ||
-                g.edge_matrix(g.edges[e].second, g.edges[e].first) != g.edge_value[e]) { std::printf("facade FAILED: edge_matrix entries\n"); return 5; }
+                std::fabs(g.edge_matrix(g.edges[e].second, g.edges[e].first) - g.edge_value[e]) > 1e-12) { std::printf("facade FAILED: edge_matrix entries\n"); return 5; }
         for (long i = 0; i < N; ++i)
             if (g.edge_matrix(i, i) != 0.0) { std::printf("facade FAILED: edge_matrix diagonal\n"); return 5; }
     }
