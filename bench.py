@@ -46,9 +46,10 @@ def main():
                     help="extra leg at N=1 (off by default: the entry point is experimental, DESIGN 6): this many independent scan "
                          "sequences on the ONE GPU stepped together through sgs_process_scans_batched_f32_dev (one registration launch "
                          "for all of them), aggregate scans/s reported as `multi_stream_batched`.  Never the headline value")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="extra leg at N=1: this many independent scan streams (one context + one host thread each) on the ONE "
-                         "GPU, aggregate scans/s reported as `multi_stream` (SURVEY.md 8d); 0 = skip.  Never the headline value")
+                         "GPU, aggregate scans/s reported as `multi_stream` (SURVEY.md 8d); 0 = skip (the default since round 2: the leg adds "
+                         "nothing - 2 streams = 1 stream, DESIGN 6, profiles/r2_bench_default.json).  Never the headline value")
     args = ap.parse_args()
 
     import torch
@@ -136,9 +137,10 @@ def main():
     kern_s = st.icp_kernel_ms_total * 1e-3
     achieved = bytes_total / kern_s / 1e9 if kern_s > 0 else 0.0
     # HBM traffic per launch of that kernel: rocprofv3 cannot run inside this process, so the number comes
-    # from the committed PMC passes of this same command (profiles/README.md, tools/pmc_traffic.py)
+    # from the committed PMC passes of this same command (profiles/README.md, tools/pmc_traffic.py); null until
+    # the passes have been taken for the current kernel
     traffic, traffic_src = None, None
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r2_pmc_traffic.json",):  # r1's passes were of the kernel with 16-byte candidate records: not this kernel's traffic
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 traffic = json.load(fh)["kernels"]["icp_persistent_kernel"]["hbm_bytes_per_launch"]
