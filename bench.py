@@ -50,7 +50,25 @@ def main():
                     help="extra leg at N=1: this many independent scan streams (one context + one host thread each) on the ONE "
                          "GPU, aggregate scans/s reported as `multi_stream` (SURVEY.md 8d); 0 = skip (the default since round 2: the leg adds "
                          "nothing - 2 streams = 1 stream, DESIGN 6, profiles/r2_bench_default.json).  Never the headline value")
+    ap.add_argument("--mode", default="sequence", choices=["sequence", "sharded"],
+                    help="sequence (default, the headline): one independent scan stream per GPU, no collective.  sharded: BASELINE.json "
+                         "configs[4] - ONE stream of dense 128-beam ~1M-point scans, the voxel map sharded by key over the --gpus ranks, "
+                         "one all-reduce of 28 doubles per Gauss-Newton iteration (strong scaling; never measured on a multi-GPU node yet)")
     args = ap.parse_args()
+
+    if args.mode == "sharded":
+        import types
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_sharded_map
+        r = bench_sharded_map.run(types.SimpleNamespace(steps=args.steps, warmup=args.warmup, shape="dense128" if args.shape == "hdl64" else args.shape,
+                                                        block_log2=3, one_gpu=False, no_graph=args.no_graph))
+        if r is not None:
+            print(json.dumps({"metric": "scans/sec (dense 128-beam ~1M-pt scans, voxel map sharded by key, 28-double all-reduce per GN iteration)",
+                              "value": round(r["scans_per_s"], 2), "unit": "scans/s", "n_gpus": r["world"], "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(r["ms_per_scan"], 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                              "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "BASELINE.json configs[4]: one stream of synthetic 128x8192 scans, map sharded over the ranks", **r}}), flush=True)
+        return
 
     import torch
     from sg_slam_amd import api, synth

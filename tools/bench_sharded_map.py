@@ -29,6 +29,13 @@ def main():
     ap.add_argument("--one-gpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     a = ap.parse_args()
+    out = run(a)
+    if out is not None:
+        print(json.dumps(out))
+
+
+def run(a):
+    """a: namespace with steps, warmup, shape, block_log2, one_gpu, no_graph.  Returns the result dict on rank 0, None elsewhere."""
     dist = Dist(backend="gloo" if a.one_gpu else None)
     dev = 0 if a.one_gpu else dist.local_rank
     ctx = api.Context(api.preset("kitti", max_points=1 << 21, map_capacity_log2=21, enable_graph=0 if a.no_graph else 1), device=dev)
@@ -48,14 +55,16 @@ def main():
     dist.barrier()
     err = max(float(np.linalg.norm(p[4:] - synth.gt_pose(a.warmup + k)[4:])) for k, p in enumerate(poses))
     vox_all = dist.sum(vox)
+    out = None
     if dist.rank == 0:
-        print(json.dumps({"mode": "key-sharded map" if dist.world > 1 else "one map", "world": dist.world,
-                          "backend": dist.backend, "shape": a.shape, "points_per_scan": int(len(scans[0][0])),
-                          "scans_per_s": a.steps / el, "ms_per_scan": 1e3 * el / a.steps, "gn_iterations_mean": float(np.mean(its)),
-                          "n_src_last": int(r["n_src"]), "voxels_rank0": int(vox), "voxels_all_ranks": int(vox_all),
-                          "max_translation_error_vs_truth_m": err, "input": "host buffers (PCIe copy inside the time)"}))
+        out = {"mode": "key-sharded map" if dist.world > 1 else "one map", "world": dist.world,
+               "backend": dist.backend, "shape": a.shape, "points_per_scan": int(len(scans[0][0])),
+               "scans_per_s": a.steps / el, "ms_per_scan": 1e3 * el / a.steps, "gn_iterations_mean": float(np.mean(its)),
+               "n_src_last": int(r["n_src"]), "voxels_rank0": int(vox), "voxels_all_ranks": int(vox_all),
+               "max_translation_error_vs_truth_m": err, "input": "host buffers (PCIe copy inside the time)"}
     ctx.close()
     dist.close()
+    return out
 
 
 if __name__ == "__main__":
