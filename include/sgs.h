@@ -273,7 +273,10 @@ int sgs_prefetch_scan_f32_dev(sgs_ctx *ctx, const float *xyzi_dev, const int32_t
  * copy synchronously.  The following sgs_process_scan_f32 call with the same (xyzi, label, n, is_kitti) picks the
  * result up.  The buffers must stay valid and unchanged until that call returns. */
 int sgs_prefetch_scan_f32(sgs_ctx *ctx, const float *xyzi, const int32_t *label, int n, int is_kitti);
-/* One step of S independent scan sequences on ONE GPU (SURVEY.md 5 "many-per-GPU"; no counterpart in the reference, whose
+/* EXPERIMENTAL (results are bit-identical to the single-sequence calls on MI355X, but it is not yet
+ * faster than one chained sequence and one unexplained GPU fault is on record for it; bench.py and the test suite only
+ * exercise it on request).
+ * One step of S independent scan sequences on ONE GPU (SURVEY.md 5 "many-per-GPU"; no counterpart in the reference, whose
  * mainProcess serves one sequence): ctxs[s] is the context of sequence s, (xyzi_dev[s], label_dev[s], n[s]) its next scan in
  * device memory.  Does for every sequence what sgs_process_scan_f32_dev does with cfg.async_map_update = 1 - same poses,
  * clouds, boxes and maps, bit for bit - but registers all S scans in ONE launch that steps their Gauss-Newton loops in
