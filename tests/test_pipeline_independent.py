@@ -10,7 +10,7 @@ HasMoved, thresholds 3 sigma and sigma / 3), frontend/Preprocessing.cpp:70-125, 
 frontend/Registration.cpp:50-177 (incl. the INCREMENTAL transform of the source cloud, :165), frontend/Registration.hpp:
 21-56, frontend/Threshold.cpp:29-50."""
 import numpy as np
-from scipy.linalg import expm
+from scipy.linalg import expm, logm
 from scipy.spatial.transform import Rotation
 
 import oracle_py as O
@@ -125,7 +125,22 @@ class PySlam:
             self.samples += 1
         return self.initial_threshold if self.samples < 1 else np.sqrt(self.sse2 / self.samples)
 
-    def process(self, xyz, lab):
+    def process(self, xyz, lab, timestamps=None, kitti=False, deskew=False):
+        self._raw = xyz
+        if deskew and timestamps is not None and len(self.poses) > 2:
+            # Deskew.cpp:37-48: exp((t_i - 0.5) * log(T0^-1 T1)) * p_i with the last two poses
+            xi = np.real(logm(np.linalg.inv(self.poses[-2]) @ self.poses[-1]))
+            ts, first = np.unique(timestamps, return_inverse=True)
+            motions = np.array([expm((t - 0.5) * xi) for t in ts])[first]
+            xyz = np.einsum("nij,nj->ni", motions[:, :3, :3], xyz) + motions[:, :3, 3]
+        if kitti:
+            # Preprocessing.cpp:127-137 on the RAW frame (SemGraphSLAM.cpp:30-33 overwrites any deskew result):
+            # rotation by 0.205 deg about normalize(p x z)
+            raw_xyz = self._raw
+            ax = np.cross(raw_xyz, [0.0, 0.0, 1.0])
+            nrm_ax = np.linalg.norm(ax, axis=1, keepdims=True)
+            ax = np.divide(ax, nrm_ax, out=np.zeros_like(ax), where=nrm_ax > 0)
+            xyz = Rotation.from_rotvec(ax * (0.205 * np.pi / 180.0)).apply(raw_xyz)
         nrm = np.sqrt(np.sum(xyz * xyz, axis=1))
         keep = (nrm < self.max_range) & (nrm > self.min_range) & (lab < 20)
         cx, cl = xyz[keep], lab[keep]
@@ -166,3 +181,22 @@ def test_numpy_pipeline_and_oracle_agree_scan_by_scan():
     for key, c, p in zip(keys.tolist(), cnt, pts):
         b = np.array(py.map.m[tuple(key)])
         assert len(b) == c and np.array_equal(b[:, 3], p[:c, 3]) and np.abs(b[:, :3] - p[:c, :3]).max() < 1e-8
+
+
+def test_numpy_pipeline_kitti_correction_and_deskew_variants():
+    """The same comparison with CorrectKITTIScan on (dataset == "kitti") and, separately, with DeSkewScan on
+    (MulRAN-style per-column timestamps); coordinates now pass through scipy's Rodrigues / matrix log + exp on one side
+    and the oracle's closed forms on the other, so keys of points on a voxel face could differ - none does here."""
+    for mode in ("kitti", "deskew"):
+        py = PySlam()
+        orc = O.Slam(O.kitti_config(enable_graph=0, deskew=1 if mode == "deskew" else 0))
+        for k in range(7):
+            xyzi, _, lab = synth.scan(k, "mini")
+            xyz = xyzi[:, :3].astype(np.float64)
+            ts = synth.mulran_timestamps(len(xyz), 16, 450) if mode == "deskew" else None
+            rp = py.process(xyz, lab, ts, kitti=(mode == "kitti"), deskew=(mode == "deskew"))
+            ro = orc.process(xyz, lab, ts, mode == "kitti")
+            for a in ("n_in", "n_cluster", "n_ds", "n_src", "map_voxels", "iterations"):
+                assert rp[a] == ro[a], f"{mode} scan {k}: {a} {rp[a]} != {ro[a]}"
+            D = np.linalg.inv(pose_matrix(ro["pose"])) @ rp["pose"]
+            assert np.linalg.norm(D[:3, 3]) < 1e-8 and Rotation.from_matrix(D[:3, :3]).magnitude() < 1e-9, (mode, k)
